@@ -1,0 +1,863 @@
+/*
+ * rt_oracle.c -- CPU restatement (plain C) of UI233/RayTracer's per-pixel render
+ * path.  TEST INFRASTRUCTURE ONLY; see rt_oracle.h for the pinning statement.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src/RayTracer/).  Nothing is hoisted or reordered: per-ray
+ * vertex transforms, per-ray matrix inverses and by-value copies are restated as
+ * the reference performs them, so that this file can check the product's
+ * upload-time precomputation bit for bit.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (see Makefile).
+ * -ffp-contract=off because the surveyed host build of the reference used it
+ * (SURVEY.md section 8(c)); rsqrtf(x) is 1.0f/sqrtf(x) as in helper_math.h:62-65.
+ */
+#include "rt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------- vectors */
+typedef struct { float x, y; } f2;
+typedef struct { float x, y, z; } f3;
+typedef struct { float x, y, z, w; } f4;
+typedef struct { float v[4][4]; } m4;
+
+static inline f3 mk3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
+static inline f4 mk4(float x, float y, float z, float w) { f4 r = { x, y, z, w }; return r; }
+/* helper_math.h:349,579,804,814,997 */
+static inline f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 mul3(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 scale3(f3 a, float b) { return mk3(a.x * b, a.y * b, a.z * b); }
+static inline f3 div3s(f3 a, float b) { return mk3(a.x / b, a.y / b, a.z / b); }
+static inline f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+/* helper_math.h:1248,1252 */
+static inline float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float dot4(f4 a, f4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+/* helper_math.h:1420 */
+static inline f3 cross3(f3 a, f3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* helper_math.h:62-65 (host rsqrtf), :1291, :1309-1318 */
+static inline float rsqrt_host(float x) { return 1.0f / sqrtf(x); }
+static inline float length3(f3 v) { return sqrtf(dot3(v, v)); }
+static inline f3 normalize3(f3 v) { float inv = rsqrt_host(dot3(v, v)); return scale3(v, inv); }
+static inline f4 normalize4(f4 v)
+{
+    float inv = rsqrt_host(dot4(v, v));
+    return mk4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
+/* ---------------------------------------------------------------- mat4 */
+/* Matrix/Matrix.cu:73-83 */
+static f4 m4_apply4(const m4 *m, f4 a)
+{
+    f4 r;
+    r.x = m->v[0][0] * a.x + m->v[0][1] * a.y + m->v[0][2] * a.z + m->v[0][3] * a.w;
+    r.y = m->v[1][0] * a.x + m->v[1][1] * a.y + m->v[1][2] * a.z + m->v[1][3] * a.w;
+    r.z = m->v[2][0] * a.x + m->v[2][1] * a.y + m->v[2][2] * a.z + m->v[2][3] * a.w;
+    r.w = m->v[3][0] * a.x + m->v[3][1] * a.y + m->v[3][2] * a.z + m->v[3][3] * a.w;
+    return r;
+}
+/* Matrix/Matrix.cu:85-91 */
+static f3 m4_apply3(const m4 *m, f3 a)
+{
+    f4 r = m4_apply4(m, mk4(a.x, a.y, a.z, 1.0f));
+    return mk3(r.x / r.w, r.y / r.w, r.z / r.w);
+}
+/* Matrix/Matrix.cu:235-243 */
+static m4 m4_transpose(const m4 *m)
+{
+    m4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.v[i][j] = m->v[j][i];
+    return r;
+}
+/* Matrix/Matrix.cu:181-233 (note factor11 repeats factor07's expression) */
+static m4 m4_inverse(const m4 *mm)
+{
+    const float (*m)[4] = mm->v;
+    float factor00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+    float factor01 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    float factor02 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+    float factor03 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    float factor04 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+    float factor05 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    float factor06 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+    float factor07 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float factor08 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+    float factor09 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+    float factor10 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+    float factor11 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float factor12 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+    float factor13 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    float factor14 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    float factor15 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    float factor16 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    float factor17 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    float factor18 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+
+    m4 I;
+    I.v[0][0] = +(m[1][1] * factor00 - m[1][2] * factor01 + m[1][3] * factor02);
+    I.v[0][1] = -(m[1][0] * factor00 - m[1][2] * factor03 + m[1][3] * factor04);
+    I.v[0][2] = +(m[1][0] * factor01 - m[1][1] * factor03 + m[1][3] * factor05);
+    I.v[0][3] = -(m[1][0] * factor02 - m[1][1] * factor04 + m[1][2] * factor05);
+
+    I.v[1][0] = -(m[0][1] * factor00 - m[0][2] * factor01 + m[0][3] * factor02);
+    I.v[1][1] = +(m[0][0] * factor00 - m[0][2] * factor03 + m[0][3] * factor04);
+    I.v[1][2] = -(m[0][0] * factor01 - m[0][1] * factor03 + m[0][3] * factor05);
+    I.v[1][3] = +(m[0][0] * factor02 - m[0][1] * factor04 + m[0][2] * factor05);
+
+    I.v[2][0] = +(m[0][1] * factor06 - m[0][2] * factor07 + m[0][3] * factor08);
+    I.v[2][1] = -(m[0][0] * factor06 - m[0][2] * factor09 + m[0][3] * factor10);
+    I.v[2][2] = +(m[0][0] * factor11 - m[0][1] * factor09 + m[0][3] * factor12);
+    I.v[2][3] = -(m[0][0] * factor08 - m[0][1] * factor10 + m[0][2] * factor12);
+
+    I.v[3][0] = -(m[0][1] * factor13 - m[0][2] * factor14 + m[0][3] * factor15);
+    I.v[3][1] = +(m[0][0] * factor13 - m[0][2] * factor16 + m[0][3] * factor17);
+    I.v[3][2] = -(m[0][0] * factor14 - m[0][1] * factor16 + m[0][3] * factor18);
+    I.v[3][3] = +(m[0][0] * factor15 - m[0][1] * factor17 + m[0][2] * factor18);
+
+    float determinant = +m[0][0] * I.v[0][0] + m[0][1] * I.v[0][1] + m[0][2] * I.v[0][2] +
+                        m[0][3] * I.v[0][3];
+
+    /* Inverse *= 1.0f / determinant  (Matrix.cu:43-51, 230) */
+    float b = 1.0f / determinant;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            I.v[i][j] *= b;
+
+    return m4_transpose(&I);
+}
+
+/* ---------------------------------------------------------------- Ray */
+/* Ray/Ray.cuh:13-28, Ray/Ray.cu:2-7: the constructor normalises. */
+typedef struct { f3 o, d; } ray_t;
+static inline ray_t mk_ray(f3 o, f3 r) { ray_t q; q.o = o; q.d = normalize3(r); return q; }
+static inline f3 ray_pos(const ray_t *r, float t) { return add3(r->o, scale3(r->d, t)); }
+
+/* ---------------------------------------------------------------- constants */
+#define ORC_INF 1000000.0f            /* Ray/IntersectionRecord.cuh:7-9 */
+#define ORC_FLOAT_EPS (1e-2f)         /* Model/Model.cuh:24-26 FLOAT_EPISLON */
+#define ORC_INV_PI 0.318309892f       /* Material/material.cu:5 */
+#define ORC_PI_OVER4 0.78539816339744830961f /* material.cu:7 */
+#define ORC_PI_OVER2 1.57079632679489661923f /* material.cu:8 */
+#define ORC_MAT_LAMBERTIAN 1          /* Material/Object.cuh:15 */
+#define ORC_MAT_SPECULAR_BIT 4        /* Material/Object.cuh:10 */
+
+/* ---------------------------------------------------------------- record */
+/* Ray/IntersectionRecord.cuh:18-36; constructor defaults :21 */
+typedef struct {
+    f3 pos, normal, tangent;
+    f3 color;
+    float t;
+    ray_t wo;
+    int lightidx;
+    float pdf_light, pdf_surface;
+    int material;      /* model index standing in for Material* */
+    int isLight;
+    int material_type;
+    int prim;          /* not in the reference: primitive index, for the id buffer */
+} rec_t;
+
+static void rec_init(rec_t *r)
+{
+    memset(r, 0, sizeof(*r));
+    r->t = ORC_INF;
+    r->isLight = 0;
+    r->lightidx = -1;
+    r->color = mk3(-1.0f, -1.0f, -1.0f);
+    r->material = -1;
+    r->prim = -1;
+}
+
+static m4 load_m4(const float *p)
+{
+    m4 m;
+    memcpy(m.v, p, sizeof(m.v));
+    return m;
+}
+
+/* ---------------------------------------------------------------- Triangle */
+/* Model/Model.cu:413-420 Triangle::area */
+static float tri_area(const m4 *M, const f3 pos[3])
+{
+    f3 rpos[3];
+    for (int i = 0; i < 3; i++)
+        rpos[i] = m4_apply3(M, pos[i]);
+    return 0.5f * length3(cross3(sub3(rpos[2], rpos[0]), sub3(rpos[1], rpos[0])));
+}
+
+/* Model/Model.cu:91-137 Triangle::hit.  g = primitive index in traversal order. */
+static int tri_hit(const orc_scene *s, int g, const ray_t *r, rec_t *c)
+{
+    const float *pp = s->tri_pos + 9 * (size_t)g;
+    const float *nn = s->tri_nrm + 9 * (size_t)g;
+    int model = s->tri_model[g];
+    m4 M = load_m4(s->model_xf + 16 * (size_t)model);
+    f3 pos[3] = { mk3(pp[0], pp[1], pp[2]), mk3(pp[3], pp[4], pp[5]), mk3(pp[6], pp[7], pp[8]) };
+    f3 nrm[3] = { mk3(nn[0], nn[1], nn[2]), mk3(nn[3], nn[4], nn[5]), mk3(nn[6], nn[7], nn[8]) };
+
+    f3 ta = m4_apply3(&M, pos[0]), tb = m4_apply3(&M, pos[1]), tc = m4_apply3(&M, pos[2]); /* :94 */
+
+    float t;
+    f3 norma = cross3(sub3(ta, tc), sub3(tb, tc));                 /* :97 */
+    float dot_normal_dir = dot3(norma, r->d);                       /* :98 */
+    if (fabsf(dot_normal_dir) < ORC_FLOAT_EPS)                      /* :99 */
+        return 0;
+
+    t = (-dot3(r->o, norma) + dot3(ta, norma)) / dot_normal_dir;    /* :102 */
+
+    f3 p = ray_pos(r, t);                                           /* :104 */
+
+    float S = 2.0f * tri_area(&M, pos);                             /* :106 */
+    float s1 = length3(cross3(sub3(p, ta), sub3(p, tb)));           /* :107 */
+    float s2 = length3(cross3(sub3(p, tc), sub3(p, ta)));           /* :108 */
+    float s3 = length3(cross3(sub3(p, tc), sub3(p, tb)));           /* :109 */
+
+    if (fabsf(s1 + s2 + s3 - S) > 0.001f)                           /* :113 */
+        return 0;
+
+    float m1 = s3 / S, m2 = s2 / S, m3 = 1.0f - m1 - m2;            /* :116 */
+
+    if (t > ORC_FLOAT_EPS && t < c->t) {                            /* :120 */
+        c->material = model;                                        /* :122 */
+        c->material_type = s->model_mat_type[model];                /* :123 */
+        c->t = t;
+        c->normal = normalize3(add3(add3(scale3(nrm[0], m1), scale3(nrm[1], m2)),
+                                    scale3(nrm[2], m3)));           /* :125 */
+        m4 inv = m4_inverse(&M);
+        m4 cas = m4_transpose(&inv);                                /* :126 */
+        f4 tmp = normalize4(m4_apply4(&cas, mk4(c->normal.x, c->normal.y, c->normal.z, 0.0f)));
+        c->normal = mk3(tmp.x, tmp.y, tmp.z);                       /* :127-128 */
+        c->pos = ray_pos(r, t);                                     /* :129 */
+        c->isLight = 0;
+        /* make_float3(0.3, 0.4, -0.5): double literals narrowed to float (:131) */
+        c->tangent = normalize3(cross3(c->normal, mk3((float)0.3, (float)0.4, (float)-0.5)));
+        c->prim = g;
+        return 1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- Quadratic */
+/* Model/Model.cu:341-346 getRadius (type Sphere = 0) */
+static float quad_radius(const orc_scene *s, int q)
+{
+    if (s->quad_type[q] == 0)
+        return (1 / s->quad_coeff[3 * q + 0]);
+    return 0.0f;
+}
+
+/* Model/Model.cu:349-410 Quadratic::hit (sphere only). */
+static int quad_hit(const orc_scene *s, int q, const ray_t *r, rec_t *c)
+{
+    if (s->quad_type[q] != 0)
+        return 0;
+    int model = s->n_tri_models + s->n_meshes + q;
+    m4 M = load_m4(s->model_xf + 16 * (size_t)model);
+
+    f3 center = mk3(0.0f, 0.0f, 0.0f);
+    m4 inv = m4_inverse(&M);                                        /* :352 */
+    f3 Lorigin = m4_apply3(&inv, r->o);                             /* :353 */
+    f4 L4dir = m4_apply4(&inv, mk4(r->d.x, r->d.y, r->d.z, 0));     /* :355 */
+    f3 Ldir = normalize3(mk3(L4dir.x, L4dir.y, L4dir.z));           /* :356 */
+    f3 oc = sub3(Lorigin, center);                                  /* :357 */
+    float dotOCD = dot3(Ldir, oc);                                  /* :358 */
+
+    if (dotOCD > 0)                                                 /* :360 */
+        return 0;
+
+    float dotOC = dot3(oc, oc);
+    float rad = quad_radius(s, q);
+    float discriminant = dotOCD * dotOCD - dotOC + rad * rad;       /* :364 */
+    float t0, t1;
+    if (discriminant < 0)
+        return 0;
+    else if (discriminant < ORC_FLOAT_EPS)
+        t0 = t1 = -dotOCD;
+    else {
+        discriminant = sqrtf(discriminant);
+        t0 = -dotOCD - discriminant;
+        t1 = -dotOCD + discriminant;
+        if (t0 < ORC_FLOAT_EPS)
+            t0 = t1;
+    }
+
+    f3 pos = add3(scale3(Ldir, t0), Lorigin);                       /* :382 */
+    f4 n4 = m4_apply4(&M, mk4(pos.x, pos.y, pos.z, 0.0f));
+    f3 normal = normalize3(mk3(n4.x, n4.y, n4.z));                  /* :383 */
+    f3 tangent;
+    if (pos.x == 0.0f && pos.y == 0.0f) {                           /* :385-386 */
+        f4 t4 = m4_apply4(&M, mk4(0.0f, 0.0f, -1.0f, 0.0f));
+        tangent = mk3(t4.x, t4.y, t4.z);
+    } else {                                                        /* :387-391, UP_VEC :2 */
+        f3 up = mk3(0.0f, rad, 0.0f);
+        f3 d = sub3(up, pos);
+        f4 u4 = m4_apply4(&M, mk4(d.x, d.y, d.z, 0.0f));
+        tangent = cross3(normal, cross3(mk3(u4.x, u4.y, u4.z), normal));
+    }
+    tangent = normalize3(tangent);                                  /* :393 */
+    pos = m4_apply3(&M, pos);                                       /* :394 */
+
+    if (t0 > ORC_FLOAT_EPS && t0 < c->t) {                          /* :396 */
+        c->material = model;
+        c->material_type = s->model_mat_type[model];
+        c->t = t0;
+        c->pos = pos;
+        c->normal = normal;
+        c->tangent = normalize3(tangent);                           /* :404 */
+        c->isLight = 0;
+        c->prim = s->n_tris + q;
+        return 1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- Scene::hit */
+/* Scene/Scene.cu:8-67 with Mesh::hit (Model/Model.cu:287-313) inlined. */
+static int scene_hit(const orc_scene *s, const ray_t *r, rec_t *rec)
+{
+    for (int j = 0; j < s->n_tri_models; j++)                       /* :17-23 */
+        tri_hit(s, j, r, rec);
+    for (int j = 0; j < s->n_meshes; j++) {                         /* :24-30 */
+        int ishit = 0;
+        int first = s->mesh_first[j], number = s->mesh_count[j];
+        for (int i = 0; i < number; i++)                            /* Model.cu:291-298 */
+            if (tri_hit(s, first + i, r, rec))
+                ishit = 1;
+        if (ishit) {                                                /* Model.cu:301-310 */
+            int model = s->n_tri_models + j;
+            rec->material = model;
+            rec->material_type = s->model_mat_type[model];
+            /* H5: Mesh::Texture is never bound; the lookup yields (-1,-1,-1). */
+            rec->color = mk3(-1.0f, -1.0f, -1.0f);
+        }
+    }
+    for (int j = 0; j < s->n_quads; j++)                            /* :31-37 */
+        quad_hit(s, j, r, rec);
+    /* triangle lights (:43-64): light_size[2] == 0 in scope */
+    return rec->t > 0.001f && rec->t < ORC_INF - 0.1f;              /* :66 */
+}
+
+/* ---------------------------------------------------------------- spawnRay */
+/* Ray/IntersectionRecord.cu:2-32: findFloatUp/Down do not change the value
+ * (`*t++` bumps the pointer) except for the zero mappings. */
+static float find_float_up(float v)
+{
+    if (v > 0.0f && v == INFINITY) return v;
+    if (v == -0.0f) return +0.0f;
+    return v;
+}
+static float find_float_down(float v)
+{
+    if (v < 0.0f && v == INFINITY) return v;
+    if (v == +0.0f) return -0.0f;
+    return v;
+}
+/* Ray/IntersectionRecord.cu:34-49 */
+static f3 offset_from_point(f3 origin, f3 normal, f3 error_bound, f3 d)
+{
+    f3 n = mk3(fabsf(normal.x), fabsf(normal.y), fabsf(normal.z));
+    f3 offset = scale3(normal, dot3(n, error_bound));
+    if (dot3(d, normal) < 0)
+        offset = neg3(offset);
+    f3 po = add3(origin, offset);
+    po.x = po.x > 0.0f ? find_float_up(po.x) : find_float_down(po.x);
+    po.y = po.y > 0.0f ? find_float_up(po.y) : find_float_down(po.y);
+    po.z = po.z > 0.0f ? find_float_up(po.z) : find_float_down(po.z);
+    return po;
+}
+/* Ray/IntersectionRecord.cuh:38-42 */
+static ray_t rec_spawn_ray(const rec_t *rec, f3 w)
+{
+    f3 ro = offset_from_point(rec->pos, rec->normal, mk3(0.01f, 0.01f, 0.01f), w);
+    return mk_ray(ro, w);
+}
+
+/* ---------------------------------------------------------------- Material */
+/* Material/Object.cu:107-115 */
+static f3 world2local(f3 normal, f3 tangent, f3 w)
+{
+    return mk3(dot3(w, tangent), dot3(w, normal), dot3(w, normalize3(cross3(tangent, normal))));
+}
+static f3 local2world(f3 normal, f3 tangent, f3 l)
+{
+    return add3(add3(scale3(tangent, l.x), scale3(normal, l.y)),
+                scale3(normalize3(cross3(tangent, normal)), l.z));
+}
+
+/* sinf/cosf of material.cu:46 are whatever libm the reference is built against
+ * (CUDA libdevice on the GPU, glibc as host code): not bit-specified.  The build
+ * fixes them as the float rounding of a double-precision Taylor evaluation made
+ * only of IEEE double mul/add/sub, so CPU and GPU agree bit for bit.  The
+ * argument range in sampleHemi is (-pi/4, 3pi/4].  tests/ checks <= 1 ulp
+ * against glibc sinf/cosf over that range. */
+static double sin_poly(double x)
+{
+    double x2 = x * x;
+    double p = -7.6471637318198164759e-13;            /* -1/15! */
+    p = p * x2 + 1.6059043836821614599e-10;           /*  1/13! */
+    p = p * x2 + -2.5052108385441718775e-08;          /* -1/11! */
+    p = p * x2 + 2.7557319223985890653e-06;           /*  1/9!  */
+    p = p * x2 + -1.9841269841269841270e-04;          /* -1/7!  */
+    p = p * x2 + 8.3333333333333333333e-03;           /*  1/5!  */
+    p = p * x2 + -1.6666666666666666667e-01;          /* -1/3!  */
+    return x + (x * x2) * p;
+}
+static double cos_poly(double x)
+{
+    double x2 = x * x;
+    double p = 4.7794773323873852974e-14;             /*  1/16! */
+    p = p * x2 + -1.1470745597729724714e-11;          /* -1/14! */
+    p = p * x2 + 2.0876756987868098979e-09;           /*  1/12! */
+    p = p * x2 + -2.7557319223985890653e-07;          /* -1/10! */
+    p = p * x2 + 2.4801587301587301587e-05;           /*  1/8!  */
+    p = p * x2 + -1.3888888888888888889e-03;          /* -1/6!  */
+    p = p * x2 + 4.1666666666666666667e-02;           /*  1/4!  */
+    p = p * x2 + -0.5;
+    return 1.0 + x2 * p;
+}
+#define ORC_PI_2_D 1.5707963267948966192
+float orc_sinf(float x)
+{
+    double xd = (double)x;
+    if (xd > 0.78539816339744830962)
+        return (float)cos_poly(xd - ORC_PI_2_D);      /* sin(x) = cos(x - pi/2) */
+    return (float)sin_poly(xd);
+}
+float orc_cosf(float x)
+{
+    double xd = (double)x;
+    if (xd > 0.78539816339744830962)
+        return (float)(-sin_poly(xd - ORC_PI_2_D));   /* cos(x) = -sin(x - pi/2) */
+    return (float)cos_poly(xd);
+}
+
+/* Material/material.cu:28-50 sampleHemi */
+static f3 sample_hemi(f2 sample)
+{
+    f2 rs;
+    rs.x = 2.0f * sample.x - 1.0f;
+    rs.y = 2.0f * sample.y - 1.0f;
+    if (rs.x == 0.0f && rs.y == 0.0f)
+        return mk3(0.0f, 0.0f, 0.0f);
+    f2 d;
+    float r, theta;
+    if (fabsf(rs.x) > fabsf(rs.y)) {
+        r = rs.x;
+        theta = ORC_PI_OVER4 * (rs.y / rs.x);
+    } else {
+        r = rs.y;
+        theta = ORC_PI_OVER2 - ORC_PI_OVER4 * (rs.x / rs.y);
+    }
+    d.x = r * orc_sinf(theta);
+    d.y = r * orc_cosf(theta);
+    float z = sqrtf(fmaxf(0.0f, 1 - d.x * d.x - d.y * d.y));
+    return mk3(d.x, z, d.y);
+}
+
+/* Material/material.cu:52-57 Lambertian::f; c = rec.color, brdf = Lambertian::color */
+static f3 lambert_f(f3 wo, f3 wi, f3 c, f3 brdf)
+{
+    if (c.x < 0.0f)
+        c = brdf;
+    return (wo.y > 0.0f && wi.y > 0.0f) ? scale3(c, ORC_INV_PI) : mk3(0.0f, 0.0f, 0.0f);
+}
+/* Material/material.cu:79-82 */
+static float lambert_pdf(f3 wo, f3 wi)
+{
+    (void)wo;
+    return wi.y > +0.0f ? wi.y * ORC_INV_PI : 0.0f;
+}
+
+static f3 model_color(const orc_scene *s, int model)
+{
+    const float *c = s->model_color + 3 * (size_t)model;
+    return mk3(c[0], c[1], c[2]);
+}
+
+/* Material/Object.cu:3-32 Material::f via IntersectionRecord.cuh:44-47 (Lambertian only;
+ * any other type returns BLACK here: out of scope). */
+static f3 rec_f(const orc_scene *s, const rec_t *rec, f3 wo, f3 wi)
+{
+    if (rec->material_type != ORC_MAT_LAMBERTIAN)
+        return mk3(0.0f, 0.0f, 0.0f);
+    return lambert_f(world2local(rec->normal, rec->tangent, wo),
+                     world2local(rec->normal, rec->tangent, wi), rec->color,
+                     model_color(s, rec->material));
+}
+/* Material/Object.cu:34-72 Material::sample_f -> material.cu:59-71 */
+static f3 rec_sample_f(const orc_scene *s, const rec_t *rec, f3 wo, f3 *wi, float *pdf, f2 sample)
+{
+    f3 rwo = world2local(rec->normal, rec->tangent, wo);
+    f3 res = mk3(0.0f, 0.0f, 0.0f);
+    *wi = mk3(0.0f, 0.0f, 0.0f);
+    *pdf = 0.0f;
+    if (rec->material_type == ORC_MAT_LAMBERTIAN) {
+        *wi = sample_hemi(sample);
+        *pdf = lambert_pdf(rwo, *wi);
+        res = lambert_f(rwo, *wi, rec->color, model_color(s, rec->material));
+    }
+    *wi = local2world(rec->normal, rec->tangent, *wi);
+    return res;
+}
+
+/* ---------------------------------------------------------------- lights */
+static int is_black(f3 x) { return length3(x) < 0.001f; }           /* Scene.cu:3-5 */
+
+/* Scene/Scene.cu:205-251 evaluateDirectLight, delta-light (point) path, with
+ * PointLight::lightIllumi (Light/Light.cu:7-14) inlined.  rec is by value. */
+static f3 eval_direct_point(const orc_scene *s, int j, rec_t rec, orc_counts *cnt)
+{
+    const float *lp = s->pl_pos + 3 * (size_t)j, *li = s->pl_illum + 3 * (size_t)j;
+    f3 lpos_ = mk3(lp[0], lp[1], lp[2]), illum = mk3(li[0], li[1], li[2]);
+
+    /* lightIllumi */
+    ray_t r = mk_ray(lpos_, sub3(rec.pos, lpos_));                  /* Light.cu:9 */
+    rec.pdf_light = 1.0f;
+    f3 dd = sub3(rec.pos, lpos_);
+    f3 color = div3s(illum, fmaxf(0.001f, dot3(dd, dd)));           /* Light.cu:13 */
+
+    f3 lpos = r.o;                                                  /* Scene.cu:213 */
+    rec_t light_rec;
+    rec_init(&light_rec);
+    int blocked = 0;
+
+    r = rec_spawn_ray(&rec, neg3(r.d));                             /* :218 */
+
+    f3 f = scale3(rec_f(s, &rec, neg3(rec.wo.d), r.d), fabsf(dot3(rec.normal, r.d))); /* :222 */
+    if (!is_black(f)) {                                             /* :224 */
+        cnt->shadow++;
+        if (scene_hit(s, &r, &light_rec)) {                         /* :225 */
+            /* H3: idx is uninitialised for delta lights; lightidx stays -1 and the
+             * comparison is restated as never-equal. */
+            blocked = length3(sub3(light_rec.pos, r.o)) < length3(sub3(r.o, lpos)) - 0.01f; /* :227 */
+        }
+    }
+
+    if (rec.pdf_light < 0.001f)                                     /* :233 */
+        return mk3(0.0f, 0.0f, 0.0f);
+
+    f3 res = mk3(0.0f, 0.0f, 0.0f);
+    if (!is_black(f) && !blocked && !is_black(color)) {             /* :236 */
+        color = div3s(mul3(color, f), rec.pdf_light);               /* :240 isDelta */
+        res = color;
+    }
+    return res;
+}
+
+/* ---------------------------------------------------------------- Philox */
+/* cuRAND Philox4x32-10 (call sites PathTracer.cu:27, Scene.cu:87, kernel.cu:47,67),
+ * restated from the published algorithm (Random123; constants as in
+ * /opt/rocm/include/rocrand/rocrand_philox4x32_10.h:62-65, round :286-303). */
+void orc_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    for (int round = 0; round < 10; round++) {
+        uint64_t m0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t hi0 = (uint32_t)(m0 >> 32), lo0 = (uint32_t)m0;
+        uint32_t hi1 = (uint32_t)(m1 >> 32), lo1 = (uint32_t)m1;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* curand_init(seed = idx + 332, subsequence = idx, offset = 0) (kernel.cu:47):
+ * key = (seed lo, seed hi), counter words 2-3 = subsequence, words 0-1 = draw
+ * number.  curand_uniform4 maps each word x to x * 2^-32 + 2^-33 (H7). */
+void orc_pixel_uniform4(uint32_t pixel_index, uint32_t draw, float out[4])
+{
+    uint64_t seed = (uint64_t)pixel_index + 332u;
+    uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t ctr[4] = { draw, 0u, pixel_index, 0u };
+    uint32_t r[4];
+    orc_philox4x32_10(ctr, key, r);
+    for (int i = 0; i < 4; i++)
+        out[i] = (float)r[i] * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+/* ---------------------------------------------------------------- Camera */
+/* Camera/Camera.cuh:17-23, Camera/Camera.cu:4-14 (pers/raster2world are dead). */
+typedef struct { f3 pos, up, front, right; int res_x, res_y; float n; } cam_t;
+static cam_t cam_make(const orc_camera_args *a)
+{
+    cam_t c;
+    f3 pos = mk3(a->pos[0], a->pos[1], a->pos[2]);
+    f3 lookat = mk3(a->lookat[0], a->lookat[1], a->lookat[2]);
+    c.pos = pos;
+    c.up = normalize3(mk3(a->up[0], a->up[1], a->up[2]));
+    c.front = normalize3(sub3(lookat, pos));
+    c.res_x = a->res_x;
+    c.res_y = a->res_y;
+    c.n = a->near_;
+    c.right = normalize3(cross3(c.front, c.up));
+    c.up = normalize3(cross3(c.right, c.front));
+    return c;
+}
+/* Camera/Camera.cu:16-24 */
+static ray_t cam_generate_ray(const cam_t *c, float x, float y)
+{
+    const float step = 0.25f;
+    float aspect = (float)c->res_x / c->res_y;
+    f3 dir = add3(add3(scale3(c->front, c->n),
+                       scale3(scale3(scale3(c->right, (float)x / c->res_x), step), aspect)),
+                  scale3(scale3(c->up, (float)y / c->res_y), step));
+    return mk_ray(c->pos, normalize3(dir));
+}
+
+/* ---------------------------------------------------------------- pathTracer */
+typedef struct { uint32_t pixel, draw; } rng_t;
+static void rng_uniform4(rng_t *g, float out[4])
+{
+    orc_pixel_uniform4(g->pixel, g->draw, out);
+    g->draw++;
+}
+
+/* Scene/Scene.cu:69-124 sampleAllLight: one curand_uniform4 per light (:87),
+ * point lights only in scope. */
+static f3 sample_all_light(const orc_scene *s, const rec_t *rec, rng_t *g, orc_counts *cnt)
+{
+    f3 res = mk3(0.0f, 0.0f, 0.0f);
+    for (int j = 0; j < s->n_point_lights; j++) {
+        float tmp[4];
+        rng_uniform4(g, tmp);
+        res = add3(res, eval_direct_point(s, j, *rec, cnt));
+    }
+    return res;
+}
+
+/* core/PathTracer.cu:11-92 with MAX_DEPTH as a run-time argument. */
+static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_counts *cnt,
+                      float *first_t, int *first_prim)
+{
+    rec_t rec;
+    int ishit;
+    float pdf;
+    f3 le, wi;
+    f3 beta = mk3(1.0f, 1.0f, 1.0f);
+    f3 res = mk3(0.0f, 0.0f, 0.0f);
+    float tmp[4];
+    for (int bounces = 0;; bounces++) {
+        rng_uniform4(g, tmp);                                       /* :27 */
+        f2 sample_scatter = { tmp[0], tmp[1] };
+        rec_init(&rec);                                             /* :29 */
+        if (bounces > max_depth) {
+            /* :31 traces this ray too, but with Lambertian surfaces and no
+             * environment light nothing reads the result before the break at :64. */
+            break;
+        }
+        ishit = scene_hit(s, &r, &rec);                             /* :31 */
+        if (bounces == 0) {
+            cnt->primary++;
+            *first_t = rec.t;
+            *first_prim = rec.prim;
+        } else {
+            cnt->bounce++;
+        }
+        rec.wo = r;                                                 /* :32 */
+        /* :33-62 emission: triangle/environment lights only, out of scope */
+        if (!ishit || bounces > max_depth)                          /* :64 */
+            break;
+        int specular = rec.material_type & ORC_MAT_SPECULAR_BIT;    /* :67 */
+        if (!specular) {
+            le = sample_all_light(s, &rec, g, cnt);                 /* :72 */
+            res = add3(res, mul3(beta, le));                        /* :73 */
+        }
+        le = rec_sample_f(s, &rec, neg3(r.d), &wi, &pdf, sample_scatter); /* :76 */
+        if (pdf < 0.0001f || length3(le) < 0.0001f)                 /* :77 */
+            return res;
+        beta = mul3(beta, div3s(scale3(le, fabsf(dot3(wi, rec.normal))), pdf)); /* :79 */
+        r = rec_spawn_ray(&rec, wi);                                /* :80 */
+        if (bounces > 3) {                                          /* :82-88 */
+            float q = 0.5f;
+            if (tmp[2] < q)
+                break;
+            beta = div3s(beta, 1.0f - q);
+        }
+    }
+    return res;
+}
+
+/* ---------------------------------------------------------------- driver */
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* kernel.cu:50-79 `debug`, with the H4 conventions: jitter = (.x,.y) of one
+ * uniform4 from the pixel's own stream, cnt = 1-based sample index. */
+int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int width, int height,
+               int x0, int y0, int x1, int y1, int spp, int max_depth, int threads,
+               float *rgba, int32_t *prim_id, float *t_out, orc_counts *counts)
+{
+    if (!scene || !cam_args || x0 < 0 || y0 < 0 || x1 > width || y1 > height || x0 >= x1 ||
+        y0 >= y1 || spp < 1)
+        return -1;
+    cam_t cam = cam_make(cam_args);
+    int cw = x1 - x0, ch = y1 - y0;
+    uint64_t n_primary = 0, n_shadow = 0, n_bounce = 0;
+#ifdef _OPENMP
+    if (threads > 0)
+        omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : n_primary, n_shadow, n_bounce)
+    for (int i = 0; i < cw * ch; i++) {
+        int x = x0 + i % cw, y = y0 + i / cw;
+        rng_t g = { (uint32_t)(y * width + x), 0u };                /* kernel.cu:46-47 */
+        f3 px = mk3(0.0f, 0.0f, 0.0f);
+        float ft = ORC_INF;
+        int fprim = -1;
+        orc_counts c = { 0, 0, 0 };
+        for (int cnt = 1; cnt <= spp; cnt++) {
+            float frac1 = 1.0f / cnt;                               /* :65 */
+            float frac2 = frac1 * (cnt - 1);                        /* :66 */
+            float j[4];
+            rng_uniform4(&g, j);                                    /* :67 (H4) */
+            float xoff = j[0], yoff = j[1];
+            ray_t r = cam_generate_ray(&cam, x - width / 2 + xoff, y - height / 2 + yoff); /* :73 */
+            f3 col = path_tracer(scene, r, &g, max_depth, &c, &ft, &fprim);             /* :74 */
+            px = add3(scale3(px, frac2), scale3(col, frac1));       /* :75 */
+        }
+        if (rgba) {
+            rgba[4 * i + 0] = px.x;
+            rgba[4 * i + 1] = px.y;
+            rgba[4 * i + 2] = px.z;
+            rgba[4 * i + 3] = 1.0f;                                 /* :77 */
+        }
+        if (prim_id) prim_id[i] = fprim;
+        if (t_out) t_out[i] = ft;
+        n_primary += c.primary;
+        n_shadow += c.shadow;
+        n_bounce += c.bounce;
+    }
+    if (counts) {
+        counts->primary = n_primary;
+        counts->shadow = n_shadow;
+        counts->bounce = n_bounce;
+    }
+    return 0;
+}
+
+int orc_scene_hit(const orc_scene *scene, int n, const float *org, const float *dir, float *t,
+                  int32_t *prim_id, int32_t *ishit)
+{
+    if (!scene || n < 0)
+        return -1;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n; i++) {
+        ray_t r = mk_ray(mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]),
+                         mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+        rec_t rec;
+        rec_init(&rec);
+        int h = scene_hit(scene, &r, &rec);
+        if (t) t[i] = rec.t;
+        if (prim_id) prim_id[i] = rec.prim;
+        if (ishit) ishit[i] = h;
+    }
+    return 0;
+}
+
+/* Camera::generateRay on explicit raster coordinates (Camera/Camera.cu:16-24). */
+int orc_camera_ray(const orc_camera_args *cam_args, int n, const float *xy, float *org, float *dir)
+{
+    if (!cam_args || n < 0)
+        return -1;
+    cam_t cam = cam_make(cam_args);
+    for (int i = 0; i < n; i++) {
+        ray_t r = cam_generate_ray(&cam, xy[2 * i], xy[2 * i + 1]);
+        org[3 * i] = r.o.x; org[3 * i + 1] = r.o.y; org[3 * i + 2] = r.o.z;
+        dir[3 * i] = r.d.x; dir[3 * i + 1] = r.d.y; dir[3 * i + 2] = r.d.z;
+    }
+    return 0;
+}
+
+/* pathTracer on one explicit camera ray (core/PathTracer.cu:11-92); the RNG
+ * stream is that of `pixel_index`, starting at draw number `draw0`. */
+int orc_trace_ray(const orc_scene *scene, const float org[3], const float dir[3], int max_depth,
+                  uint32_t pixel_index, uint32_t draw0, float rgb[3], float *t, int32_t *prim)
+{
+    if (!scene)
+        return -1;
+    ray_t r = mk_ray(mk3(org[0], org[1], org[2]), mk3(dir[0], dir[1], dir[2]));
+    rng_t g = { pixel_index, draw0 };
+    orc_counts c = { 0, 0, 0 };
+    float ft = ORC_INF;
+    int fp = -1;
+    f3 col = path_tracer(scene, r, &g, max_depth, &c, &ft, &fp);
+    rgb[0] = col.x; rgb[1] = col.y; rgb[2] = col.z;
+    if (t) *t = ft;
+    if (prim) *prim = fp;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- post-process */
+/* PostProcess/PostProcess.cuh:11-18, 29-37 (HDR = ACES filmic), :39-56 */
+static float saturate1(float v) { return fminf(1.0f, fmaxf(0.0f, v)); }
+static float aces1(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return saturate1((x * (a * x + b)) / (x * (c * x + d) + e));
+}
+void orc_tonemap_aces(int n_px, const float *in, float *out)
+{
+    for (int i = 0; i < n_px; i++) {
+        out[4 * i + 0] = aces1(in[4 * i + 0]);
+        out[4 * i + 1] = aces1(in[4 * i + 1]);
+        out[4 * i + 2] = aces1(in[4 * i + 2]);
+        out[4 * i + 3] = 1.0f;
+    }
+}
+
+/* PostProcess/PostProcess.cuh:59-104 filterKernel: 3x3 window gathered x-major
+ * (i = x-1..x+1 outer, j = y-1..y+1 inner), the reference's own exchange sort by
+ * luma (descending), output element count/2. */
+void orc_median3x3(int width, int height, const float *in, float *out)
+{
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            f4 temp[10];
+            float ty[10];
+            int count = 0;
+            for (int i = x - 1; i <= x + 1; i++)
+                for (int j = y - 1; j <= y + 1; j++)
+                    if (i >= 0 && i < width && j >= 0 && j < height) {
+                        const float *c = in + 4 * ((size_t)j * width + i);
+                        temp[count] = mk4(c[0], c[1], c[2], c[3]);
+                        ty[count++] = 0.299f * c[0] + 0.587f * c[1] + 0.114f * c[2];
+                    }
+            for (int i = 0; i < count; i++)
+                for (int j = 0; j < i; j++)
+                    if (ty[i] > ty[j]) {
+                        float sf = ty[i];
+                        f4 s4 = temp[i];
+                        ty[i] = ty[j];
+                        temp[i] = temp[j];
+                        ty[j] = sf;
+                        temp[j] = s4;
+                    }
+            float *o = out + 4 * ((size_t)y * width + x);
+            o[0] = temp[count / 2].x;
+            o[1] = temp[count / 2].y;
+            o[2] = temp[count / 2].z;
+            o[3] = temp[count / 2].w;
+        }
+}

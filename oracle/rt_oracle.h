@@ -1,0 +1,121 @@
+/*
+ * rt_oracle.h -- CPU restatement of UI233/RayTracer's per-pixel render path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped path:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library, and only as the checker.  The product (raytracer_amd/) never
+ * links, imports or calls it.
+ *
+ * PARITY PINNING.  The reference has no tests, golden images or fixtures
+ * (SURVEY.md section 4), and its hot-path translation units cannot be built in
+ * this image without hand-written stand-ins for cuda_runtime.h / curand_kernel.h /
+ * libcudart, which the build rules forbid.  The only outputs of the reference
+ * itself that exist are the three known answers the surveyor recorded from the
+ * reference's own code; tests/test_oracle_pins.py checks
+ * this restatement against the one that is fully specified (sphere + point light,
+ * 64x48, centre pixel: t = 5.005611, radiance (0.244406, 0.010100, 0.011608)).
+ * Everything else is "parity unpinned": the oracle is a line-by-line restatement
+ * of the reference arithmetic (each function cites the file:line it follows),
+ * compiled -O2 -ffp-contract=off.  cuRAND Philox semantics are restated from the
+ * published Philox4x32-10 algorithm (Random123 known-answer vectors are checked);
+ * equality with a real CUDA cuRAND stream is unpinned.
+ *
+ * Conventions fixed by decision where the reference is racy/undefined
+ * (SURVEY.md section 8 hazards H3, H4, H5, H7) are listed in DESIGN.md.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Flat scene description: the 11 arguments of Scene::initializeScene
+ * (reference Scene/Scene.cuh:16-17) flattened to POD arrays.
+ * Triangles are listed in the reference's traversal order
+ * (Scene/Scene.cu:13-41): standalone Triangle models first, then each Mesh's
+ * meshTable in order.  Models are numbered: standalone triangles
+ * [0, n_tri_models), meshes [n_tri_models, n_tri_models+n_meshes), quadrics
+ * after that -- the same order initializeScene walks mat_type[] / mat[]
+ * (Scene/Scene.cu:143-149). */
+typedef struct orc_scene {
+    int32_t n_tri_models;     /* model_size[0] */
+    int32_t n_meshes;         /* model_size[1] */
+    int32_t n_quads;          /* model_size[2] */
+    int32_t n_tris;           /* n_tri_models + sum of mesh triangle counts */
+    const float *tri_pos;     /* [n_tris][3][3]  Triangle::pos  (object space) */
+    const float *tri_nrm;     /* [n_tris][3][3]  Triangle::normal             */
+    const int32_t *tri_model; /* [n_tris] owning model index                  */
+    const int32_t *mesh_first;/* [n_meshes] first triangle of mesh j          */
+    const int32_t *mesh_count;/* [n_meshes] Mesh::number                      */
+    const float *model_xf;    /* [n_models][16] Model::transformation, row-major */
+    const int32_t *model_mat_type; /* [n_models] material::MATERIAL_TYPE      */
+    const float *model_color; /* [n_models][3] Lambertian::color              */
+    const float *quad_coeff;  /* [n_quads][3] Quadratic::coefficient          */
+    const int32_t *quad_type; /* [n_quads]   quadraticType (0 = Sphere)       */
+    int32_t n_point_lights;   /* light_size[0] */
+    const float *pl_pos;      /* [n_point_lights][3] */
+    const float *pl_illum;    /* [n_point_lights][3] */
+} orc_scene;
+
+/* The 7 constructor arguments of Camera (reference Camera/Camera.cuh:11). */
+typedef struct orc_camera_args {
+    float pos[3];
+    float lookat[3];
+    float fov, near_, far_;
+    int32_t res_x, res_y;     /* the reference passes (W/2, H/2): kernel.cu:228-229 */
+    float up[3];
+} orc_camera_args;
+
+typedef struct orc_counts {
+    uint64_t primary;   /* camera rays traced                                   */
+    uint64_t shadow;    /* shadow rays actually cast (Scene.cu:224-225)         */
+    uint64_t bounce;    /* Scene::hit calls at bounces >= 1 whose result is used */
+} orc_counts;
+
+/* Render the crop [x0,x1) x [y0,y1) of a width x height image for `spp`
+ * progressive samples (cnt = 1..spp), restating kernel.cu:50-79 with the H4
+ * conventions.  Outputs are crop-sized, row-major (y - y0, x - x0):
+ *   rgba    [h][w][4]  running mean, alpha = 1           (may be NULL)
+ *   prim_id [h][w]     primary-hit primitive of the LAST sample, -1 = miss
+ *   t       [h][w]     rec.t of that primary hit (INF = 1e6 on miss)
+ * threads <= 0 -> OpenMP default.  Returns 0 on success. */
+int orc_render(const orc_scene *scene, const orc_camera_args *cam,
+               int width, int height, int x0, int y0, int x1, int y1,
+               int spp, int max_depth, int threads,
+               float *rgba, int32_t *prim_id, float *t, orc_counts *counts);
+
+/* Scene::hit on explicit rays (Scene/Scene.cu:8-67).  dir is normalised by the
+ * Ray constructor exactly as the reference does (Ray/Ray.cu:2).
+ * Writes t (INF on miss), prim id (-1) and the return value of Scene::hit. */
+int orc_scene_hit(const orc_scene *scene, int n, const float *org, const float *dir,
+                  float *t, int32_t *prim_id, int32_t *ishit);
+
+/* Camera::generateRay (Camera/Camera.cu:16-24) for n raster points xy[n][2]. */
+int orc_camera_ray(const orc_camera_args *cam, int n, const float *xy, float *org, float *dir);
+
+/* pathTracer (core/PathTracer.cu:11-92) on one explicit ray, RNG stream of
+ * `pixel_index` starting at draw `draw0`. */
+int orc_trace_ray(const orc_scene *scene, const float org[3], const float dir[3], int max_depth,
+                  uint32_t pixel_index, uint32_t draw0, float rgb[3], float *t, int32_t *prim);
+
+/* Philox4x32-10 block and the cuRAND-style float mapping (H7). */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_pixel_uniform4(uint32_t pixel_index, uint32_t draw, float out[4]);
+
+/* The deterministic sinf/cosf the build fixes for sampleHemi (material.cu:46). */
+float orc_sinf(float x);
+float orc_cosf(float x);
+
+/* Post-process restatements (PostProcess/PostProcess.cuh:29-37, 59-104). */
+void orc_tonemap_aces(int n_px, const float *rgba_in, float *rgba_out);
+void orc_median3x3(int width, int height, const float *rgba_in, float *rgba_out);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,232 @@
+"""Flat scene / camera containers shared by the C-ABI binding, tests and bench.
+
+``SceneData`` is the 11-argument call of the reference's
+``Scene::initializeScene`` (Scene/Scene.cuh:16-17) flattened to numpy arrays, in
+the reference's traversal order (Scene/Scene.cu:13-41): standalone ``Triangle``
+models first, then each ``Mesh``'s triangles, then ``Quadratic`` models.
+``CameraArgs`` is the 7-argument ``Camera`` constructor (Camera/Camera.cuh:11).
+
+``SceneDesc``/``CameraDesc`` are the ctypes mirrors of ``rt_scene_desc`` /
+``rt_camera_desc`` in include/rt_abi.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MAT_LAMBERTIAN = 1  # material::LAMBERTIAN, Material/Object.cuh:15
+QUAD_SPHERE = 0     # quadraticType::Sphere, Model/Model.cuh:100-103
+
+
+def _f32(a, shape):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    return a.reshape(shape)
+
+
+def _i32(a, shape):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+    return a.reshape(shape)
+
+
+def identity():
+    return np.eye(4, dtype=np.float32)
+
+
+def translation(x, y, z):
+    """Matrix/Matrix.cu:143-151."""
+    m = np.eye(4, dtype=np.float32)
+    m[0, 3], m[1, 3], m[2, 3] = x, y, z
+    return m
+
+
+def scale(x, y, z):
+    """Matrix/Matrix.cu:170-179."""
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0], m[1, 1], m[2, 2] = x, y, z
+    return m
+
+
+@dataclass
+class CameraArgs:
+    pos: tuple = (0.0, 0.0, 0.0)
+    lookat: tuple = (0.0, 0.0, -1.0)
+    fov: float = 2.0
+    near: float = 0.1
+    far: float = 1000.0
+    res: tuple = (0, 0)          # the reference passes (W/2, H/2), kernel.cu:228-229
+    up: tuple = (0.0, 1.0, 0.0)
+
+    @staticmethod
+    def for_image(width, height, **kw):
+        return CameraArgs(res=(width // 2, height // 2), **kw)
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("lookat", C.c_float * 3), ("fov", C.c_float),
+                ("near_", C.c_float), ("far_", C.c_float), ("res_x", C.c_int32),
+                ("res_y", C.c_int32), ("up", C.c_float * 3)]
+
+    @staticmethod
+    def from_args(a: CameraArgs) -> "CameraDesc":
+        d = CameraDesc()
+        d.pos[:] = [float(v) for v in a.pos]
+        d.lookat[:] = [float(v) for v in a.lookat]
+        d.fov, d.near_, d.far_ = float(a.fov), float(a.near), float(a.far)
+        d.res_x, d.res_y = int(a.res[0]), int(a.res[1])
+        d.up[:] = [float(v) for v in a.up]
+        return d
+
+
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int32)
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_tri_models", C.c_int32), ("n_meshes", C.c_int32), ("n_quads", C.c_int32),
+                ("n_tris", C.c_int32), ("tri_pos", _FP), ("tri_nrm", _FP), ("tri_model", _IP),
+                ("mesh_first", _IP), ("mesh_count", _IP), ("model_xf", _FP),
+                ("model_mat_type", _IP), ("model_color", _FP), ("quad_coeff", _FP),
+                ("quad_type", _IP), ("n_point_lights", C.c_int32), ("pl_pos", _FP),
+                ("pl_illum", _FP)]
+
+
+@dataclass
+class SceneData:
+    """Host-side scene, caller-owned; uploads copy it (as the reference does)."""
+    n_tri_models: int = 0
+    tri_pos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3, 3), np.float32))
+    tri_nrm: np.ndarray = field(default_factory=lambda: np.zeros((0, 3, 3), np.float32))
+    tri_model: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    mesh_first: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    mesh_count: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    model_xf: np.ndarray = field(default_factory=lambda: np.zeros((0, 4, 4), np.float32))
+    model_mat_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    model_color: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    quad_coeff: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    quad_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    pl_pos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    pl_illum: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+
+    @property
+    def n_tris(self):
+        return int(self.tri_pos.shape[0])
+
+    @property
+    def n_meshes(self):
+        return int(self.mesh_first.shape[0])
+
+    @property
+    def n_quads(self):
+        return int(self.quad_coeff.shape[0])
+
+    @property
+    def n_models(self):
+        return self.n_tri_models + self.n_meshes + self.n_quads
+
+    @property
+    def n_prims(self):
+        return self.n_tris + self.n_quads
+
+    @property
+    def n_lights(self):
+        return int(self.pl_pos.shape[0])
+
+    def normalise(self):
+        n = self.tri_pos.shape[0] if self.tri_pos.ndim == 3 else np.asarray(self.tri_pos).size // 9
+        self.tri_pos = _f32(self.tri_pos, (n, 3, 3))
+        self.tri_nrm = _f32(self.tri_nrm, (n, 3, 3))
+        self.tri_model = _i32(self.tri_model, (n,))
+        self.mesh_first = _i32(self.mesh_first, (-1,))
+        self.mesh_count = _i32(self.mesh_count, (-1,))
+        self.quad_coeff = _f32(self.quad_coeff, (-1, 3))
+        self.quad_type = _i32(self.quad_type, (-1,))
+        nm = self.n_tri_models + self.mesh_first.shape[0] + self.quad_coeff.shape[0]
+        self.model_xf = _f32(self.model_xf, (nm, 4, 4))
+        self.model_mat_type = _i32(self.model_mat_type, (nm,))
+        self.model_color = _f32(self.model_color, (nm, 3))
+        self.pl_pos = _f32(self.pl_pos, (-1, 3))
+        self.pl_illum = _f32(self.pl_illum, (-1, 3))
+        assert self.pl_pos.shape == self.pl_illum.shape
+        assert self.quad_type.shape[0] == self.quad_coeff.shape[0]
+        assert int(self.mesh_count.sum()) + self.n_tri_models == n
+        return self
+
+    def desc(self) -> SceneDesc:
+        """ctypes view; keeps no copies, so `self` must outlive the call."""
+        self.normalise()
+        d = SceneDesc()
+        d.n_tri_models, d.n_meshes, d.n_quads = self.n_tri_models, self.n_meshes, self.n_quads
+        d.n_tris = self.n_tris
+        fp = lambda a: a.ctypes.data_as(_FP)
+        ip = lambda a: a.ctypes.data_as(_IP)
+        d.tri_pos, d.tri_nrm, d.tri_model = fp(self.tri_pos), fp(self.tri_nrm), ip(self.tri_model)
+        d.mesh_first, d.mesh_count = ip(self.mesh_first), ip(self.mesh_count)
+        d.model_xf, d.model_mat_type = fp(self.model_xf), ip(self.model_mat_type)
+        d.model_color = fp(self.model_color)
+        d.quad_coeff, d.quad_type = fp(self.quad_coeff), ip(self.quad_type)
+        d.n_point_lights = self.n_lights
+        d.pl_pos, d.pl_illum = fp(self.pl_pos), fp(self.pl_illum)
+        return d
+
+
+class SceneBuilder:
+    """Mirrors how the reference's host code assembles a scene before
+    ``initializeScene`` (kernel.cu:268-313): models by type, one material each."""
+
+    def __init__(self):
+        self._tris = []      # (pos[3,3], nrm[3,3], xf, color)
+        self._meshes = []    # (pos[n,3,3], nrm[n,3,3], xf, color)
+        self._quads = []     # (coeff, type, xf, color)
+        self._lights = []
+
+    def add_triangle(self, pos, nrm, xf=None, color=(0.7, 0.7, 0.7)):
+        self._tris.append((_f32(pos, (3, 3)), _f32(nrm, (3, 3)),
+                           identity() if xf is None else _f32(xf, (4, 4)), color))
+        return self
+
+    def add_mesh(self, pos, nrm, xf=None, color=(0.7, 0.7, 0.7)):
+        pos = _f32(pos, (-1, 3, 3))
+        self._meshes.append((pos, _f32(nrm, pos.shape),
+                             identity() if xf is None else _f32(xf, (4, 4)), color))
+        return self
+
+    def add_sphere(self, coeff_x, xf=None, color=(0.7, 0.7, 0.7)):
+        """Quadratic(make_float3(c, 0, 0), Sphere): radius = 1/c (Model.cu:341-346)."""
+        self._quads.append(((coeff_x, 0.0, 0.0), QUAD_SPHERE,
+                            identity() if xf is None else _f32(xf, (4, 4)), color))
+        return self
+
+    def add_point_light(self, pos, illum):
+        self._lights.append((pos, illum))
+        return self
+
+    def build(self) -> SceneData:
+        s = SceneData()
+        s.n_tri_models = len(self._tris)
+        pos, nrm, model, xf, col = [], [], [], [], []
+        for i, (p, n, m, c) in enumerate(self._tris):
+            pos.append(p[None]); nrm.append(n[None]); model.append(np.full(1, i, np.int32))
+            xf.append(m); col.append(c)
+        first, count = [], []
+        cursor = len(self._tris)
+        for j, (p, n, m, c) in enumerate(self._meshes):
+            pos.append(p); nrm.append(n)
+            model.append(np.full(p.shape[0], s.n_tri_models + j, np.int32))
+            first.append(cursor); count.append(p.shape[0]); cursor += p.shape[0]
+            xf.append(m); col.append(c)
+        for (_, _, m, c) in self._quads:
+            xf.append(m); col.append(c)
+        s.tri_pos = np.concatenate(pos) if pos else np.zeros((0, 3, 3), np.float32)
+        s.tri_nrm = np.concatenate(nrm) if nrm else np.zeros((0, 3, 3), np.float32)
+        s.tri_model = np.concatenate(model) if model else np.zeros((0,), np.int32)
+        s.mesh_first, s.mesh_count = np.array(first, np.int32), np.array(count, np.int32)
+        s.model_xf = np.array(xf, np.float32).reshape(-1, 4, 4)
+        s.model_mat_type = np.full(len(xf), MAT_LAMBERTIAN, np.int32)
+        s.model_color = np.array(col, np.float32).reshape(-1, 3)
+        s.quad_coeff = np.array([q[0] for q in self._quads], np.float32).reshape(-1, 3)
+        s.quad_type = np.array([q[1] for q in self._quads], np.int32)
+        s.pl_pos = np.array([l[0] for l in self._lights], np.float32).reshape(-1, 3)
+        s.pl_illum = np.array([l[1] for l in self._lights], np.float32).reshape(-1, 3)
+        return s.normalise()

@@ -1,0 +1,589 @@
+// rt_context.hip -- implementation of the C ABI (include/rt_abi.h): context, device
+// memory, scene/camera upload, the per-sample launch sequence, readback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "rt_kernels.h"
+#include "rt_upload.h"
+
+using namespace rt;
+
+namespace {
+
+constexpr uint32_t kMaxBatch = 1u << 21;     // paths per wavefront batch
+constexpr int kLightsPerPass = 64;           // bits of the per-path shadow mask
+
+thread_local std::string g_err;              // for calls that have no context yet
+
+} // namespace
+
+struct rt_context {
+    int device = 0;
+    int width = 0, height = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;          // everything freed by rt_destroy
+    std::vector<void *> scene_allocs;    // freed on re-upload
+    std::vector<void *> part_allocs;     // freed on re-partition
+
+    int rank = 0, world = 1, tile = 64;
+    uint32_t n_local = 0;
+    std::vector<uint32_t> h_pixmap;
+    uint32_t batch = 0;                  // queue capacity (paths)
+    size_t shadow_cap = 0;               // shadow queue capacity (rays)
+
+    bool have_scene = false, have_cam = false;
+    int n_lights = 0;
+    uint64_t n_prims = 0;
+    int max_blocks = 2048;
+
+    DevView v{};
+    int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
+
+    // stats
+    uint64_t samples = 0, primary = 0, launches = 0;
+    double intersect_ms = 0.0, render_ms = 0.0;
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;
+
+    // readback staging (full image)
+    float4 *img_rgba = nullptr, *img_tmp = nullptr;
+    int32_t *img_prim = nullptr;
+    float *img_t = nullptr;
+};
+
+namespace {
+
+int fail(rt_context *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define RT_HIP(c, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), RT_ERR_DEVICE,                                                    \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+template <class T>
+int dalloc(rt_context *c, std::vector<void *> &owner, T *&p, size_t n)
+{
+    p = nullptr;
+    if (n == 0) n = 1;
+    void *q = nullptr;
+    RT_HIP(c, hipMalloc(&q, n * sizeof(T)));
+    owner.push_back(q);
+    p = (T *)q;
+    return RT_OK;
+}
+
+void free_all(std::vector<void *> &owner)
+{
+    for (void *p : owner) (void)hipFree(p);
+    owner.clear();
+}
+
+int alloc_queue(rt_context *c, std::vector<void *> &owner, RayQueue &q, size_t n, bool with_path)
+{
+    int rc;
+    if ((rc = dalloc(c, owner, q.ox, n))) return rc;
+    if ((rc = dalloc(c, owner, q.oy, n))) return rc;
+    if ((rc = dalloc(c, owner, q.oz, n))) return rc;
+    if ((rc = dalloc(c, owner, q.dx, n))) return rc;
+    if ((rc = dalloc(c, owner, q.dy, n))) return rc;
+    if ((rc = dalloc(c, owner, q.dz, n))) return rc;
+    q.path = nullptr;
+    if (with_path && (rc = dalloc(c, owner, q.path, n))) return rc;
+    return RT_OK;
+}
+
+// Pixel-tile partition: tiles row-major over the image,
+// tile_id % world == rank; inside a tile, 8x8 pixel blocks so that one wave
+// (64 consecutive local indices) covers a compact square of the image.
+void build_pixmap(rt_context *c)
+{
+    const int W = c->width, H = c->height, T = c->tile;
+    const int ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
+    c->h_pixmap.clear();
+    for (int ty = 0; ty < nty; ty++)
+        for (int tx = 0; tx < ntx; tx++) {
+            int tile_id = ty * ntx + tx;
+            if (tile_id % c->world != c->rank)
+                continue;
+            for (int by = 0; by < T; by += 8)
+                for (int bx = 0; bx < T; bx += 8)
+                    for (int iy = 0; iy < 8; iy++)
+                        for (int ix = 0; ix < 8; ix++) {
+                            int x = tx * T + bx + ix, y = ty * T + by + iy;
+                            if (bx + ix < T && by + iy < T && x < W && y < H)
+                                c->h_pixmap.push_back((uint32_t)(y * W + x));
+                        }
+        }
+    c->n_local = (uint32_t)c->h_pixmap.size();
+}
+
+int alloc_shadow(rt_context *c)
+{
+    // (re)size the shadow queue for the current batch size and light count
+    size_t need = (size_t)c->batch * (size_t)std::max(1, std::min(c->n_lights, kLightsPerPass));
+    if (need <= c->shadow_cap)
+        return RT_OK;
+    // shadow buffers live with the partition allocations; growing re-partitions lazily
+    int rc;
+    if ((rc = alloc_queue(c, c->part_allocs, c->v.shadow, need, false))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, c->v.sh_thr, need))) return rc;
+    for (int k = 0; k < 3; k++)
+        if ((rc = dalloc(c, c->part_allocs, c->v.sh_contrib[k], need))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, c->v.sh_hit_t, need))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, c->v.sh_hit_id, need))) return rc;
+    c->shadow_cap = need;
+    return RT_OK;
+}
+
+int setup_partition(rt_context *c)
+{
+    free_all(c->part_allocs);
+    c->shadow_cap = 0;
+    build_pixmap(c);
+    const size_t n = c->n_local;
+    c->batch = (uint32_t)std::min<size_t>(std::max<size_t>(n, 1), kMaxBatch);
+    DevView &v = c->v;
+    int rc;
+    uint32_t *pixmap = nullptr;
+    if ((rc = dalloc(c, c->part_allocs, pixmap, n))) return rc;
+    if (n)
+        RT_HIP(c, hipMemcpy(pixmap, c->h_pixmap.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    v.pixmap = pixmap;
+    if ((rc = dalloc(c, c->part_allocs, v.rng_ctr, n))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.fb, n))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.first_id, n))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.first_t, n))) return rc;
+    for (int k = 0; k < 3; k++) {
+        if ((rc = dalloc(c, c->part_allocs, v.beta[k], n))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, v.res[k], n))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, v.le[k], n))) return rc;
+    }
+    if ((rc = dalloc(c, c->part_allocs, v.bounce_draw, n))) return rc;
+    const size_t b = c->batch;
+    for (int k = 0; k < 2; k++)
+        if ((rc = alloc_queue(c, c->part_allocs, v.rays[k], b, true))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.hit_t, b))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.hit_id, b))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.sh_mask, b))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.sh_base, b / 64 + 2))) return rc;
+    if ((rc = alloc_shadow(c))) return rc;
+    return RT_OK;
+}
+
+int do_reset(rt_context *c)
+{
+    const size_t n = c->n_local;
+    DevView &v = c->v;
+    if (n) {
+        RT_HIP(c, hipMemsetAsync(v.rng_ctr, 0, n * sizeof(uint32_t), c->stream));
+        RT_HIP(c, hipMemsetAsync(v.fb, 0, n * sizeof(float4), c->stream));
+        RT_HIP(c, hipMemsetAsync(v.first_t, 0, n * sizeof(float), c->stream));
+        launch_fill_i32(c->stream, v.first_id, n, -1);
+    }
+    RT_HIP(c, hipMemsetAsync(v.sh_base, 0, (c->batch / 64 + 2) * sizeof(uint32_t), c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->cnt = 0;
+    return RT_OK;
+}
+
+hipEvent_t next_event(rt_context *c)
+{
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess)
+            return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+// One closest-hit launch, optionally bracketed by HIP events on the launch stream.
+void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, uint32_t cap,
+                     float *out_t, int32_t *out_id)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        e0 = next_event(c);
+        e1 = next_event(c);
+    }
+    if (e0) (void)hipEventRecord(e0, c->stream);
+    launch_intersect(c->stream, c->v, q, count, cap, out_t, out_id, c->max_blocks);
+    if (e1) (void)hipEventRecord(e1, c->stream);
+    c->launches++;
+}
+
+} // namespace
+
+// =====================================================================================
+extern "C" const char *rt_last_error(const rt_context *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_err.c_str();
+}
+
+extern "C" int rt_create(rt_context **out, int device, int width, int height)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "ctx out-pointer is NULL");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (long long)width * height > 0x7fffffffLL)
+        return fail(nullptr, RT_ERR_INVALID, "bad image size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, RT_ERR_DEVICE, "no HIP device: this library needs a gfx950 GPU");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, RT_ERR_INVALID, "device index out of range");
+    rt_context *c = new rt_context();
+    c->device = device;
+    c->width = width;
+    c->height = height;
+    c->v.width = width;
+    c->v.height = height;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_r0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_r1);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        std::string m = std::string("rt_create: ") + hipGetErrorString(e);
+        delete c;
+        return fail(nullptr, RT_ERR_DEVICE, m);
+    }
+    c->max_blocks = std::max(1, prop.multiProcessorCount) * 8;
+    int rc = dalloc(c, c->allocs, c->v.ctl, 1);
+    if (rc == RT_OK && hipMemset(c->v.ctl, 0, sizeof(Ctl)) != hipSuccess) rc = RT_ERR_DEVICE;
+    if (rc == RT_OK) rc = setup_partition(c);
+    if (rc == RT_OK) rc = do_reset(c);
+    if (rc != RT_OK) {
+        std::string m = c->err;
+        rt_destroy(c);
+        return fail(nullptr, rc, m);
+    }
+    *out = c;
+    return RT_OK;
+}
+
+extern "C" int rt_destroy(rt_context *c)
+{
+    if (!c) return RT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_all(c->part_allocs);
+    free_all(c->scene_allocs);
+    free_all(c->allocs);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_r0) (void)hipEventDestroy(c->ev_r0);
+    if (c->ev_r1) (void)hipEventDestroy(c->ev_r1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_HIP(c, hipSetDevice(c->device));
+    HostScene hs;
+    std::string err;
+    int rc = build_host_scene(d, hs, err);
+    if (rc != RT_OK) return fail(c, rc, err);
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    free_all(c->scene_allocs);
+    c->have_scene = false;
+    DevView &v = c->v;
+    TriRec *tris = nullptr; TriCold *cold = nullptr; ModelRec *models = nullptr;
+    SphereRec *spheres = nullptr; LightRec *lights = nullptr;
+    if ((rc = dalloc(c, c->scene_allocs, tris, hs.tris.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, cold, hs.cold.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, models, hs.models.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, spheres, hs.spheres.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, lights, hs.lights.size()))) return rc;
+    auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    RT_HIP(c, up(tris, hs.tris.data(), hs.tris.size() * sizeof(TriRec)));
+    RT_HIP(c, up(cold, hs.cold.data(), hs.cold.size() * sizeof(TriCold)));
+    RT_HIP(c, up(models, hs.models.data(), hs.models.size() * sizeof(ModelRec)));
+    RT_HIP(c, up(spheres, hs.spheres.data(), hs.spheres.size() * sizeof(SphereRec)));
+    RT_HIP(c, up(lights, hs.lights.data(), hs.lights.size() * sizeof(LightRec)));
+    v.tris = tris; v.tri_cold = cold; v.models = models; v.spheres = spheres; v.lights = lights;
+    v.n_tris = (int)hs.tris.size();
+    v.n_spheres = (int)hs.spheres.size();
+    v.n_lights = (int)hs.lights.size();
+    c->n_lights = v.n_lights;
+    c->n_prims = (uint64_t)hs.tris.size() + hs.spheres.size();
+    if ((rc = alloc_shadow(c))) return rc;
+    c->have_scene = true;
+    return RT_OK;
+}
+
+extern "C" int rt_set_camera(rt_context *c, const rt_camera_desc *cam)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!cam) return fail(c, RT_ERR_INVALID, "camera is NULL");
+    if (cam->res_x <= 0 || cam->res_y <= 0) return fail(c, RT_ERR_INVALID, "camera resolution must be positive");
+    c->v.cam = make_camera(cam);
+    c->have_cam = true;
+    return RT_OK;
+}
+
+extern "C" int rt_set_partition(rt_context *c, int rank, int world, int tile)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (world < 1 || rank < 0 || rank >= world || tile < 8 || (tile % 8) != 0)
+        return fail(c, RT_ERR_INVALID, "need 0 <= rank < world and tile a positive multiple of 8");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    c->rank = rank; c->world = world; c->tile = tile;
+    int rc = setup_partition(c);
+    if (rc != RT_OK) return rc;
+    return do_reset(c);
+}
+
+extern "C" int rt_reset(rt_context *c)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_HIP(c, hipSetDevice(c->device));
+    return do_reset(c);
+}
+
+extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene || !c->have_cam)
+        return fail(c, RT_ERR_STATE, "rt_render needs rt_upload_scene and rt_set_camera first");
+    if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
+    RT_HIP(c, hipSetDevice(c->device));
+    DevView &v = c->v;
+    const int L = c->n_lights;
+    const int n_pass = std::max(1, (L + kLightsPerPass - 1) / kLightsPerPass);
+    hipStream_t s = c->stream;
+    RT_HIP(c, hipEventRecord(c->ev_r0, s));
+    for (int smp = 0; smp < n_samples; smp++) {
+        c->cnt++;
+        v.cnt = c->cnt;
+        c->ev_used = 0;
+        for (uint32_t p0 = 0; p0 < c->n_local; p0 += c->batch) {
+            const uint32_t n = std::min(c->batch, c->n_local - p0);
+            launch_ctl_begin(s, v.ctl, n);
+            launch_gen(s, v, p0, n);
+            int cur = 0;
+            for (int bounce = 0; bounce <= max_depth; bounce++) {
+                timed_intersect(c, v.rays[cur], &v.ctl->n_cur, n, v.hit_t, v.hit_id);
+                for (int pass = 0; pass < n_pass; pass++) {
+                    const int l0 = pass * kLightsPerPass;
+                    const int nl = std::max(0, std::min(kLightsPerPass, L - l0));
+                    launch_shade(s, v, n, cur, bounce, l0, nl, L, c->max_blocks);
+                    if (nl > 0)
+                        timed_intersect(c, v.shadow, &v.ctl->n_shadow, (uint32_t)std::min<size_t>((size_t)n * nl, 0xffffffffu),
+                                        v.sh_hit_t, v.sh_hit_id);
+                    launch_finish(s, v, n, cur, bounce, max_depth, l0, nl, pass == n_pass - 1,
+                                  c->max_blocks);
+                    launch_ctl_after_shadow(s, v.ctl);
+                }
+                launch_ctl_next_bounce(s, v.ctl);
+                cur ^= 1;
+            }
+            c->primary += n;
+        }
+        c->samples += c->n_local;
+        if (c->timing) {
+            RT_HIP(c, hipStreamSynchronize(s));
+            for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess)
+                    c->intersect_ms += ms;
+            }
+        }
+    }
+    RT_HIP(c, hipEventRecord(c->ev_r1, s));
+    RT_HIP(c, hipStreamSynchronize(s));          // cudaStreamSynchronize, kernel.cu:123
+    RT_HIP(c, hipGetLastError());
+    float ms = 0.0f;
+    RT_HIP(c, hipEventElapsedTime(&ms, c->ev_r0, c->ev_r1));
+    c->render_ms += ms;
+    return RT_OK;
+}
+
+static int ensure_image_staging(rt_context *c)
+{
+    if (c->img_rgba) return RT_OK;
+    const size_t n = (size_t)c->width * c->height;
+    int rc;
+    if ((rc = dalloc(c, c->allocs, c->img_rgba, n))) return rc;
+    if ((rc = dalloc(c, c->allocs, c->img_tmp, n))) return rc;
+    if ((rc = dalloc(c, c->allocs, c->img_prim, n))) return rc;
+    if ((rc = dalloc(c, c->allocs, c->img_t, n))) return rc;
+    return RT_OK;
+}
+
+static int scatter_full_image(rt_context *c)
+{
+    int rc = ensure_image_staging(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->width * c->height;
+    hipStream_t s = c->stream;
+    RT_HIP(c, hipMemsetAsync(c->img_rgba, 0, n * sizeof(float4), s));
+    RT_HIP(c, hipMemsetAsync(c->img_t, 0, n * sizeof(float), s));
+    launch_fill_i32(s, c->img_prim, n, -2);
+    launch_scatter_image(s, c->v.pixmap, c->n_local, c->v.fb, c->v.first_id, c->v.first_t,
+                         c->img_rgba, c->img_prim, c->img_t);
+    RT_HIP(c, hipStreamSynchronize(s));
+    return RT_OK;
+}
+
+extern "C" int rt_read_framebuffer(rt_context *c, float *rgba, int32_t *prim_id, float *t)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_HIP(c, hipSetDevice(c->device));
+    int rc = scatter_full_image(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->width * c->height;
+    if (rgba) RT_HIP(c, hipMemcpy(rgba, c->img_rgba, n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (prim_id) RT_HIP(c, hipMemcpy(prim_id, c->img_prim, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (t) RT_HIP(c, hipMemcpy(t, c->img_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_local_pixel_count(rt_context *c, int64_t *count)
+{
+    if (!c || !count) return fail(c, RT_ERR_INVALID, "NULL argument");
+    *count = (int64_t)c->n_local;
+    return RT_OK;
+}
+
+extern "C" int rt_local_pixel_indices(rt_context *c, int32_t *indices)
+{
+    if (!c || !indices) return fail(c, RT_ERR_INVALID, "NULL argument");
+    std::memcpy(indices, c->h_pixmap.data(), c->h_pixmap.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
+extern "C" int rt_export_local_rgba(rt_context *c, void *device_dst)
+{
+    if (!c || !device_dst) return fail(c, RT_ERR_INVALID, "NULL argument");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (c->n_local)
+        RT_HIP(c, hipMemcpyAsync(device_dst, c->v.fb, (size_t)c->n_local * sizeof(float4),
+                                 hipMemcpyDeviceToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float *dir, float *t,
+                            int32_t *prim_id, int32_t *ishit)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene) return fail(c, RT_ERR_STATE, "rt_scene_hit needs rt_upload_scene first");
+    if (n < 0 || (n > 0 && (!org || !dir))) return fail(c, RT_ERR_INVALID, "bad ray arrays");
+    if (n == 0) return RT_OK;
+    RT_HIP(c, hipSetDevice(c->device));
+    std::vector<void *> tmp;
+    RayQueue q{};
+    float *d_org = nullptr, *d_dir = nullptr, *d_t = nullptr;
+    int32_t *d_id = nullptr, *d_hit = nullptr;
+    uint32_t *d_count = nullptr;
+    int rc = alloc_queue(c, tmp, q, (size_t)n, false);
+    if (!rc) rc = dalloc(c, tmp, d_org, (size_t)n * 3);
+    if (!rc) rc = dalloc(c, tmp, d_dir, (size_t)n * 3);
+    if (!rc) rc = dalloc(c, tmp, d_t, (size_t)n);
+    if (!rc) rc = dalloc(c, tmp, d_id, (size_t)n);
+    if (!rc) rc = dalloc(c, tmp, d_hit, (size_t)n);
+    if (!rc) rc = dalloc(c, tmp, d_count, 1);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        uint32_t un = (uint32_t)n;
+        hipStream_t s = c->stream;
+        e = hipMemcpyAsync(d_org, org, (size_t)n * 12, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_count, &un, 4, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            launch_prepare_rays(s, q, d_org, d_dir, un);
+            launch_intersect(s, c->v, q, d_count, un, d_t, d_id, c->max_blocks);
+            launch_ishit(s, d_t, d_hit, un);
+            e = hipStreamSynchronize(s);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess && t) e = hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && prim_id) e = hipMemcpy(prim_id, d_id, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && ishit) e = hipMemcpy(ishit, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost);
+    }
+    free_all(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, std::string("rt_scene_hit: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+extern "C" int rt_postprocess(rt_context *c, float *hdr_rgba, float *filtered_rgba)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (c->world != 1)
+        return fail(c, RT_ERR_STATE, "rt_postprocess needs the whole image on one context (world = 1)");
+    RT_HIP(c, hipSetDevice(c->device));
+    int rc = scatter_full_image(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->width * c->height;
+    hipStream_t s = c->stream;
+    // render -> HDR -> filter (kernel.cu:249-251): raw in img_rgba, HDR in img_tmp
+    launch_tonemap(s, c->img_rgba, c->img_tmp, (uint32_t)n);
+    RT_HIP(c, hipStreamSynchronize(s));
+    if (hdr_rgba) RT_HIP(c, hipMemcpy(hdr_rgba, c->img_tmp, n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (filtered_rgba) {
+        launch_median3x3(s, c->img_tmp, c->img_rgba, c->width, c->height);
+        RT_HIP(c, hipStreamSynchronize(s));
+        RT_HIP(c, hipMemcpy(filtered_rgba, c->img_rgba, n * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    RT_HIP(c, hipGetLastError());
+    return RT_OK;
+}
+
+extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
+{
+    if (!c || !st) return fail(c, RT_ERR_INVALID, "NULL argument");
+    RT_HIP(c, hipSetDevice(c->device));
+    Ctl h;
+    RT_HIP(c, hipMemcpy(&h, c->v.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    st->samples = c->samples;
+    st->primary_rays = c->primary;
+    st->shadow_rays = h.shadow_total;
+    st->bounce_rays = h.bounce_total;
+    st->intersect_launches = c->launches;
+    st->intersect_ms = c->intersect_ms;
+    st->render_ms = c->render_ms;
+    st->n_prims = c->n_prims;
+    return RT_OK;
+}
+
+extern "C" int rt_reset_stats(rt_context *c)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemset(c->v.ctl, 0, sizeof(Ctl)));
+    c->samples = c->primary = c->launches = 0;
+    c->intersect_ms = c->render_ms = 0.0;
+    return RT_OK;
+}
+
+extern "C" int rt_set_timing(rt_context *c, int enabled)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    c->timing = enabled != 0;
+    return RT_OK;
+}

@@ -1,0 +1,328 @@
+// rt_device.h -- per-ray device functions of the render path (gfx950).
+// Each function names the reference code it restates (paths relative to
+// src/RayTracer/).  Ray-independent sub-expressions are NOT recomputed here:
+// they arrive precomputed in TriRec / ModelRec / SphereRec (rt_math.h) with the
+// reference's own operation order, so the bits are the same.
+#pragma once
+
+#include "rt_math.h"
+
+namespace rt {
+
+struct Ray { v3 o, d; };
+
+// Ray::Ray(o, r): direction = normalize(r)   (Ray/Ray.cu:2)
+__device__ __forceinline__ Ray make_ray(v3 o, v3 r) { Ray q; q.o = o; q.d = normalize(r); return q; }
+__device__ __forceinline__ v3 ray_pos(const Ray &r, float t) { return add(r.o, scale(r.d, t)); }  // Ray.cu:4-7
+
+// ------------------------------------------------------------------ RNG (H7)
+// Philox4x32-10 as cuRAND's curandStatePhilox4_32_10_t generates it
+// (core/PathTracer.cuh:4; call sites PathTracer.cu:27, Scene.cu:87).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int round = 0; round < 10; round++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// curand_init(seed = idx + 332, subsequence = idx, offset = 0) (kernel.cu:46-47) then
+// the `draw`-th curand_uniform4: x * 2^-32 + 2^-33.
+__device__ __forceinline__ void pixel_uniform4(uint32_t pixel, uint32_t draw, float u[4])
+{
+    uint64_t seed = (uint64_t)pixel + 332u;
+    uint32_t r[4];
+    philox4x32_10(draw, 0u, pixel, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        u[i] = (float)r[i] * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+
+// ------------------------------------------------------------------ sinf / cosf
+// material.cu:46 calls the platform libm; the build fixes both as the float
+// rounding of a double Taylor evaluation (IEEE mul/add only), identical on the
+// CPU oracle and here.  Argument range in sampleHemi: (-pi/4, 3pi/4].
+__device__ __forceinline__ double sin_poly(double x)
+{
+    double x2 = x * x;
+    double p = -7.6471637318198164759e-13;
+    p = p * x2 + 1.6059043836821614599e-10;
+    p = p * x2 + -2.5052108385441718775e-08;
+    p = p * x2 + 2.7557319223985890653e-06;
+    p = p * x2 + -1.9841269841269841270e-04;
+    p = p * x2 + 8.3333333333333333333e-03;
+    p = p * x2 + -1.6666666666666666667e-01;
+    return x + (x * x2) * p;
+}
+__device__ __forceinline__ double cos_poly(double x)
+{
+    double x2 = x * x;
+    double p = 4.7794773323873852974e-14;
+    p = p * x2 + -1.1470745597729724714e-11;
+    p = p * x2 + 2.0876756987868098979e-09;
+    p = p * x2 + -2.7557319223985890653e-07;
+    p = p * x2 + 2.4801587301587301587e-05;
+    p = p * x2 + -1.3888888888888888889e-03;
+    p = p * x2 + 4.1666666666666666667e-02;
+    p = p * x2 + -0.5;
+    return 1.0 + x2 * p;
+}
+__device__ __forceinline__ float det_sinf(float x)
+{
+    double xd = (double)x;
+    if (xd > 0.78539816339744830962)
+        return (float)cos_poly(xd - 1.5707963267948966192);
+    return (float)sin_poly(xd);
+}
+__device__ __forceinline__ float det_cosf(float x)
+{
+    double xd = (double)x;
+    if (xd > 0.78539816339744830962)
+        return (float)(-sin_poly(xd - 1.5707963267948966192));
+    return (float)cos_poly(xd);
+}
+
+// ------------------------------------------------------------------ camera
+// Camera::generateRay (Camera/Camera.cu:16-24)
+__device__ __forceinline__ Ray camera_ray(const CameraRec &c, float x, float y)
+{
+    const float step = 0.25f;
+    float aspect = (float)c.res_x / c.res_y;
+    v3 dir = add(add(scale(c.front, c.n),
+                     scale(scale(scale(c.right, (float)x / c.res_x), step), aspect)),
+                 scale(scale(c.up, (float)y / c.res_y), step));
+    return make_ray(c.pos, normalize(dir));
+}
+
+// ------------------------------------------------------------------ triangle
+// Triangle::hit (Model/Model.cu:91-137) for one (ray, triangle) pair, against the
+// running closest t.  The acceptance conditions are a pure conjunction, so the
+// cheap window test of :120 is evaluated before the area test of :106-113.
+// Returns true and the new t when the reference would update colideRec.
+__device__ __forceinline__ bool tri_hit(const TriRec &T, const v3 &o, const v3 &d, float best,
+                                        float &t_out)
+{
+    float dnd = T.nx * d.x + T.ny * d.y + T.nz * d.z;                 // :98
+    if (fabsf(dnd) < kEps)                                             // :99
+        return false;
+    float t = (-(o.x * T.nx + o.y * T.ny + o.z * T.nz) + T.dn) / dnd;  // :102
+    if (!(t > kEps && t < best))                                       // :120
+        return false;
+    float px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;  // :104
+    float ax = px - T.ax, ay = py - T.ay, az = pz - T.az;
+    float bx = px - T.bx, by = py - T.by, bz = pz - T.bz;
+    float cx = px - T.cx, cy = py - T.cy, cz = pz - T.cz;
+    v3 c1 = cross(mk3(ax, ay, az), mk3(bx, by, bz));                   // :107
+    v3 c2 = cross(mk3(cx, cy, cz), mk3(ax, ay, az));                   // :108
+    v3 c3 = cross(mk3(cx, cy, cz), mk3(bx, by, bz));                   // :109
+    float s1 = length(c1), s2 = length(c2), s3 = length(c3);
+    if (fabsf(s1 + s2 + s3 - T.S) > 0.001f)                            // :113
+        return false;
+    t_out = t;
+    return true;
+}
+
+// ------------------------------------------------------------------ sphere
+// Quadratic::hit (Model/Model.cu:349-410) up to the acceptance test :396.
+__device__ __forceinline__ bool sphere_hit(const SphereRec &S, const v3 &o, const v3 &d, float best,
+                                           float &t_out)
+{
+    if (S.type != 0)
+        return false;
+    v3 Lo = apply3(S.inv, o);                                          // :353
+    v3 Ld = normalize(apply_dir(S.inv, d));                            // :355-356
+    v3 oc = sub(Lo, mk3(0.0f, 0.0f, 0.0f));                            // :357
+    float dotOCD = dot(Ld, oc);                                        // :358
+    if (dotOCD > 0)                                                    // :360
+        return false;
+    float dotOC = dot(oc, oc);
+    float disc = dotOCD * dotOCD - dotOC + S.rad2;                     // :364
+    float t0, t1;
+    if (disc < 0)
+        return false;
+    else if (disc < kEps)
+        t0 = t1 = -dotOCD;
+    else {
+        disc = sqrtf(disc);
+        t0 = -dotOCD - disc;
+        t1 = -dotOCD + disc;
+        if (t0 < kEps)
+            t0 = t1;
+    }
+    if (t0 > kEps && t0 < best) {                                      // :396
+        t_out = t0;
+        return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------ hit record
+// The fields of IntersectRecord (Ray/IntersectionRecord.cuh:18-36) the path reads.
+struct Hit {
+    v3 pos, normal, tangent;
+    v3 color;      // rec.color; (-1,-1,-1) = "use the BRDF's colour" (material.cu:54-55, H5)
+    int model;
+};
+
+// Winner-only part of Triangle::hit (Model.cu:116-132): pure functions of
+// (triangle, ray, t).
+__device__ __forceinline__ void fill_tri_hit(const TriRec &T, const TriCold &C, const ModelRec &M,
+                                             const Ray &r, Hit &h)
+{
+    const v3 &o = r.o, &d = r.d;
+    float dnd = T.nx * d.x + T.ny * d.y + T.nz * d.z;
+    float t = (-(o.x * T.nx + o.y * T.ny + o.z * T.nz) + T.dn) / dnd;
+    v3 p = ray_pos(r, t);
+    v3 ta = mk3(T.ax, T.ay, T.az), tb = mk3(T.bx, T.by, T.bz), tc = mk3(T.cx, T.cy, T.cz);
+    float s2 = length(cross(sub(p, tc), sub(p, ta)));
+    float s3 = length(cross(sub(p, tc), sub(p, tb)));
+    float m1 = s3 / T.S, m2 = s2 / T.S, m3 = 1.0f - m1 - m2;           // :116
+    v3 n0 = mk3(C.n0[0], C.n0[1], C.n0[2]), n1 = mk3(C.n1[0], C.n1[1], C.n1[2]),
+       n2 = mk3(C.n2[0], C.n2[1], C.n2[2]);
+    v3 n = normalize(add(add(scale(n0, m1), scale(n1, m2)), scale(n2, m3)));     // :125
+    v4 tmp = normalize(apply4(M.cas, mk4(n.x, n.y, n.z, 0.0f)));       // :126-127 (float4 normalize)
+    h.normal = mk3(tmp.x, tmp.y, tmp.z);                               // :128
+    h.pos = ray_pos(r, t);                                             // :129
+    h.tangent = normalize(cross(h.normal, mk3((float)0.3, (float)0.4, (float)-0.5)));  // :131
+    h.color = mk3(-1.0f, -1.0f, -1.0f);                                // H5: unbound mesh texture
+    h.model = C.model;
+}
+
+// Winner-only part of Quadratic::hit (Model.cu:382-404).
+__device__ __forceinline__ void fill_sphere_hit(const SphereRec &S, const Ray &r, Hit &h)
+{
+    v3 Lo = apply3(S.inv, r.o);
+    v3 Ld = normalize(apply_dir(S.inv, r.d));
+    v3 oc = sub(Lo, mk3(0.0f, 0.0f, 0.0f));
+    float dotOCD = dot(Ld, oc);
+    float dotOC = dot(oc, oc);
+    float disc = dotOCD * dotOCD - dotOC + S.rad2;
+    float t0, t1;
+    if (disc < kEps)
+        t0 = t1 = -dotOCD;
+    else {
+        disc = sqrtf(disc);
+        t0 = -dotOCD - disc;
+        t1 = -dotOCD + disc;
+        if (t0 < kEps)
+            t0 = t1;
+    }
+    v3 pos = add(scale(Ld, t0), Lo);                                   // :382
+    v3 normal = normalize(apply_dir(S.M, pos));                        // :383
+    v3 tangent;
+    if (pos.x == 0.0f && pos.y == 0.0f)                                // :385-386
+        tangent = apply_dir(S.M, mk3(0.0f, 0.0f, -1.0f));
+    else                                                               // :387-391, UP_VEC :2
+        tangent = cross(normal, cross(apply_dir(S.M, sub(mk3(0.0f, S.rad, 0.0f), pos)), normal));
+    tangent = normalize(tangent);                                      // :393
+    h.pos = apply3(S.M, pos);                                          // :394
+    h.normal = normal;
+    h.tangent = normalize(tangent);                                    // :404
+    h.color = mk3(-1.0f, -1.0f, -1.0f);
+    h.model = S.model;
+}
+
+// World-space position the reference stores in rec.pos for a hit (triangle:
+// Model.cu:129; sphere: Model.cu:382,394) -- what the shadow test reads (Scene.cu:227).
+__device__ __forceinline__ v3 hit_pos_sphere(const SphereRec &S, const Ray &r, float t0)
+{
+    v3 Lo = apply3(S.inv, r.o);
+    v3 Ld = normalize(apply_dir(S.inv, r.d));
+    return apply3(S.M, add(scale(Ld, t0), Lo));
+}
+
+// ------------------------------------------------------------------ spawnRay
+// offsetFromPoint (Ray/IntersectionRecord.cu:34-49).  findFloatUp/Down
+// (:2-32) leave the value unchanged (`*t++` moves the pointer) except that a
+// zero comes back as -0.0f through findFloatDown (:22-23).
+__device__ __forceinline__ float nudge(float v)
+{
+    if (v > 0.0f)
+        return v;                       // findFloatUp: v > 0 is never -0.0f
+    if (v == 0.0f)
+        return -0.0f;                   // findFloatDown(+-0) -> -0.0f
+    return v;
+}
+__device__ __forceinline__ v3 offset_from_point(v3 origin, v3 normal, v3 eb, v3 d)
+{
+    v3 n = mk3(fabsf(normal.x), fabsf(normal.y), fabsf(normal.z));
+    v3 offset = scale(normal, dot(n, eb));
+    if (dot(d, normal) < 0)
+        offset = neg(offset);
+    v3 po = add(origin, offset);
+    return mk3(nudge(po.x), nudge(po.y), nudge(po.z));
+}
+// IntersectRecord::spawnRay (Ray/IntersectionRecord.cuh:38-42)
+__device__ __forceinline__ Ray spawn_ray(const Hit &h, v3 w)
+{
+    return make_ray(offset_from_point(h.pos, h.normal, mk3(0.01f, 0.01f, 0.01f), w), w);
+}
+
+// ------------------------------------------------------------------ material
+// Material::world2Local / local2World (Material/Object.cu:107-115)
+__device__ __forceinline__ float local_y(const Hit &h, v3 w) { return dot(w, h.normal); }
+__device__ __forceinline__ v3 local2world(const Hit &h, v3 l)
+{
+    return add(add(scale(h.tangent, l.x), scale(h.normal, l.y)),
+               scale(normalize(cross(h.tangent, h.normal)), l.z));
+}
+// Lambertian::f (Material/material.cu:52-57) on the local y components.
+__device__ __forceinline__ v3 lambert_f(float wo_y, float wi_y, v3 c, const ModelRec &M)
+{
+    if (c.x < 0.0f)
+        c = mk3(M.color[0], M.color[1], M.color[2]);
+    return (wo_y > 0.0f && wi_y > 0.0f) ? scale(c, kInvPi) : mk3(0.0f, 0.0f, 0.0f);
+}
+// Material::f (Material/Object.cu:3-32); only LAMBERTIAN is in scope, every other
+// type evaluates to BLACK here (rt_upload_scene rejects them up front).
+__device__ __forceinline__ v3 rec_f(const Hit &h, const ModelRec &M, v3 wo, v3 wi)
+{
+    if (M.mat_type != kMatLambertian)
+        return mk3(0.0f, 0.0f, 0.0f);
+    return lambert_f(local_y(h, wo), local_y(h, wi), h.color, M);
+}
+// sampleHemi (Material/material.cu:28-50)
+__device__ __forceinline__ v3 sample_hemi(float sx, float sy)
+{
+    float rx = 2.0f * sx - 1.0f, ry = 2.0f * sy - 1.0f;
+    if (rx == 0.0f && ry == 0.0f)
+        return mk3(0.0f, 0.0f, 0.0f);
+    float r, theta;
+    if (fabsf(rx) > fabsf(ry)) {
+        r = rx;
+        theta = kPiOver4 * (ry / rx);
+    } else {
+        r = ry;
+        theta = kPiOver2 - kPiOver4 * (rx / ry);
+    }
+    float dx = r * det_sinf(theta), dy = r * det_cosf(theta);
+    float z = sqrtf(fmaxf(0.0f, 1 - dx * dx - dy * dy));
+    return mk3(dx, z, dy);
+}
+// Material::sample_f -> Lambertian::sample_f (Object.cu:34-72, material.cu:59-82)
+__device__ __forceinline__ v3 rec_sample_f(const Hit &h, const ModelRec &M, v3 wo, v3 &wi,
+                                           float &pdf, float sx, float sy)
+{
+    v3 res = mk3(0.0f, 0.0f, 0.0f);
+    v3 wl = mk3(0.0f, 0.0f, 0.0f);
+    pdf = 0.0f;
+    if (M.mat_type == kMatLambertian) {
+        float wo_y = local_y(h, wo);
+        wl = sample_hemi(sx, sy);
+        pdf = wl.y > +0.0f ? wl.y * kInvPi : 0.0f;
+        res = lambert_f(wo_y, wl.y, h.color, M);
+    }
+    wi = local2world(h, wl);
+    return res;
+}
+
+__device__ __forceinline__ bool is_black(v3 x) { return length(x) < 0.001f; }   // Scene.cu:3-5
+
+} // namespace rt

@@ -1,0 +1,82 @@
+// rt_kernels.h -- device-side views and kernel launchers (internal to the library).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rt_math.h"
+
+namespace rt {
+
+// Queue lengths and ray totals, resident in device memory so that a whole
+// sample is enqueued without reading anything back.
+struct Ctl {
+    uint32_t n_cur;        // active paths of the current bounce
+    uint32_t n_next;       // survivors pushed for the next bounce
+    uint32_t n_shadow;     // shadow rays pushed by the current light pass
+    uint32_t pad;
+    unsigned long long shadow_total;   // shadow rays cast since rt_reset_stats
+    unsigned long long bounce_total;   // bounce (>= 1) rays traced since rt_reset_stats
+};
+
+// Struct-of-arrays ray queue: lane i of a wave reads element base + i of each array.
+struct RayQueue {
+    float *ox, *oy, *oz, *dx, *dy, *dz;
+    uint32_t *path;        // local path (pixel) index; unused for shadow queues
+};
+
+struct DevView {
+    int width, height;
+    int cnt;                        // 1-based sample index (*cnt of kernel.cu:52-66)
+    CameraRec cam;
+    // scene (read-only)
+    const TriRec *tris;
+    const TriCold *tri_cold;
+    const ModelRec *models;
+    const SphereRec *spheres;
+    const LightRec *lights;
+    int n_tris, n_spheres, n_lights;
+    // persistent per local pixel
+    const uint32_t *pixmap;         // local index -> global pixel index y*W + x
+    uint32_t *rng_ctr;              // next Philox draw of the pixel's stream
+    float4 *fb;                     // RGBA32F running mean
+    int32_t *first_id;
+    float *first_t;
+    // per-sample path state, per local pixel
+    float *beta[3], *res[3], *le[3];
+    uint32_t *bounce_draw;
+    // per queue position (batch-sized)
+    RayQueue rays[2];
+    float *hit_t;
+    int32_t *hit_id;
+    unsigned long long *sh_mask;
+    uint32_t *sh_base;
+    // shadow-ray queue
+    RayQueue shadow;
+    float *sh_thr;
+    float *sh_contrib[3];
+    float *sh_hit_t;
+    int32_t *sh_hit_id;
+    Ctl *ctl;
+};
+
+void launch_ctl_begin(hipStream_t s, Ctl *ctl, uint32_t n);
+void launch_ctl_after_shadow(hipStream_t s, Ctl *ctl);
+void launch_ctl_next_bounce(hipStream_t s, Ctl *ctl);
+void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n);
+void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
+                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks);
+void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
+                  int nl, int n_lights_total, int max_blocks);
+void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,
+                   int max_depth, int l0, int nl, int last_pass, int max_blocks);
+void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,
+                          const int32_t *first_id, const float *first_t, float4 *rgba,
+                          int32_t *prim, float *t);
+void launch_fill_i32(hipStream_t s, int32_t *a, size_t n, int32_t value);
+void launch_prepare_rays(hipStream_t s, const RayQueue &q, const float *org, const float *dir,
+                         uint32_t n);
+void launch_ishit(hipStream_t s, const float *t, int32_t *ishit, uint32_t n);
+void launch_tonemap(hipStream_t s, const float4 *in, float4 *out, uint32_t n);
+void launch_median3x3(hipStream_t s, const float4 *in, float4 *out, int width, int height);
+
+} // namespace rt

@@ -1,0 +1,567 @@
+// rt_kernels.hip -- gfx950 kernels of the per-pixel render path and their launchers.
+//
+// Wavefront organisation (one lane = one ray, 64-wide waves):
+//   k_gen        ray generation            kernel.cu:65-73   (jitter + Camera::generateRay)
+//   k_intersect  closest hit, brute force  Scene/Scene.cu:8-67 -> Model/Model.cu:91-137, 349-410
+//   k_shade      per light: illumination, BRDF, shadow-ray spawn with ballot compaction
+//                                          Scene/Scene.cu:69-124, 205-225; Light/Light.cu:7-14
+//   k_intersect  (again) on the compacted shadow-ray queue      Scene.cu:225
+//   k_finish     blocked test + accumulate, BRDF sampling, roulette, next-ray
+//                compaction, framebuffer running mean
+//                                          Scene.cu:227-251; core/PathTracer.cu:73-88; kernel.cu:65-77
+// All queue lengths live in device memory (Ctl), kernels are grid-stride over
+// 64-ray chunks, so a whole sample is enqueued without a host round trip.
+#include "rt_kernels.h"
+
+#include "rt_device.h"
+
+namespace rt {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr float kHitMax = kInf - 0.1f;      // Scene.cu:66
+
+__device__ __forceinline__ bool scene_ishit(float t) { return t > 0.001f && t < kHitMax; }   // Scene.cu:66
+
+// ------------------------------------------------------------------ control
+__global__ void k_ctl_begin(Ctl *ctl, uint32_t n)
+{
+    ctl->n_cur = n;
+    ctl->n_next = 0;
+    ctl->n_shadow = 0;
+}
+__global__ void k_ctl_after_shadow(Ctl *ctl)
+{
+    ctl->shadow_total += ctl->n_shadow;
+    ctl->n_shadow = 0;
+}
+__global__ void k_ctl_next_bounce(Ctl *ctl)
+{
+    ctl->bounce_total += ctl->n_next;
+    ctl->n_cur = ctl->n_next;
+    ctl->n_next = 0;
+}
+
+// ------------------------------------------------------------------ ray generation
+// One lane per local pixel of the batch [p0, p0 + n).  kernel.cu:65-73 with the H4
+// convention: the jitter is (.x, .y) of one curand_uniform4 of the pixel's own stream.
+__global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t n)
+{
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    uint32_t p = p0 + i;
+    uint32_t pix = v.pixmap[p];
+    int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
+    uint32_t draw = v.rng_ctr[p];
+    float u[4];
+    pixel_uniform4(pix, draw, u);
+    v.rng_ctr[p] = draw + 1;
+    Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
+    RayQueue q = v.rays[0];
+    q.ox[i] = r.o.x; q.oy[i] = r.o.y; q.oz[i] = r.o.z;
+    q.dx[i] = r.d.x; q.dy[i] = r.d.y; q.dz[i] = r.d.z;
+    q.path[i] = p;
+    // pathTracer locals (PathTracer.cu:19-20): beta = 1, res = 0
+    v.beta[0][p] = 1.0f; v.beta[1][p] = 1.0f; v.beta[2][p] = 1.0f;
+    v.res[0][p] = 0.0f; v.res[1][p] = 0.0f; v.res[2][p] = 0.0f;
+}
+
+// ------------------------------------------------------------------ closest hit
+// Scene::hit (Scene.cu:8-67): every ray against every primitive in the reference's
+// order -- triangles (standalone models, then each mesh's table), then quadrics.
+// A wave owns 64 rays; the triangle record is wave-uniform, so it is fetched
+// through the scalar data path (s_load) and consumed as SGPR operands.  Strict
+// `t < best` in ascending index order keeps the first primitive on exact ties (H8).
+__global__ __launch_bounds__(kBlock) void k_intersect(const TriRec *__restrict__ tris, int n_tris,
+                                                      const SphereRec *__restrict__ spheres,
+                                                      int n_spheres, RayQueue q,
+                                                      const uint32_t *__restrict__ count_ptr,
+                                                      float *__restrict__ out_t,
+                                                      int32_t *__restrict__ out_id)
+{
+    const uint32_t count = *count_ptr;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
+        uint32_t i = base + lane;
+        bool valid = i < count;
+        v3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 0.0f);
+        if (valid) {
+            o = mk3(q.ox[i], q.oy[i], q.oz[i]);
+            d = mk3(q.dx[i], q.dy[i], q.dz[i]);
+        }
+        float best = kInf;                  // IntersectRecord(): t = INF
+        int32_t id = -1;
+        for (int g = 0; g < n_tris; g++) {
+            const TriRec T = tris[g];
+            float t;
+            if (tri_hit(T, o, d, best, t)) {
+                best = t;
+                id = g;
+            }
+        }
+        for (int s = 0; s < n_spheres; s++) {
+            float t;
+            if (sphere_hit(spheres[s], o, d, best, t)) {
+                best = t;
+                id = n_tris + s;
+            }
+        }
+        if (valid) {
+            out_t[i] = best;
+            out_id[i] = id;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hit record
+__device__ __forceinline__ void fill_hit(const DevView &v, const Ray &r, int32_t id, Hit &h)
+{
+    if (id < v.n_tris)
+        fill_tri_hit(v.tris[id], v.tri_cold[id], v.models[v.tri_cold[id].model], r, h);
+    else
+        fill_sphere_hit(v.spheres[id - v.n_tris], r, h);
+}
+
+// kernel.cu:65-66,75,77: running mean over progressive samples, alpha = 1.
+__device__ __forceinline__ void finalize_path(const DevView &v, uint32_t p, v3 res)
+{
+    float frac1 = 1.0f / v.cnt;
+    float frac2 = frac1 * (v.cnt - 1);
+    float4 prev = v.fb[p];
+    float4 out;
+    out.x = frac2 * prev.x + frac1 * res.x;
+    out.y = frac2 * prev.y + frac1 * res.y;
+    out.z = frac2 * prev.z + frac1 * res.z;
+    out.w = 1.0f;
+    v.fb[p] = out;
+}
+
+// One point light against one hit: PointLight::lightIllumi (Light/Light.cu:7-14)
+// and Scene::evaluateDirectLight up to the shadow-ray test (Scene.cu:212-224).
+struct LightSample { Ray sr; v3 contrib; float thr; bool cast; };
+__device__ __forceinline__ LightSample sample_point_light(const Hit &h, const ModelRec &M,
+                                                         const v3 &wo_dir, const LightRec &L)
+{
+    LightSample s;
+    v3 lp = mk3(L.pos[0], L.pos[1], L.pos[2]), illum = mk3(L.illum[0], L.illum[1], L.illum[2]);
+    Ray wi = make_ray(lp, sub(h.pos, lp));                                  // Light.cu:9
+    v3 dd = sub(h.pos, lp);
+    v3 color = divs(illum, fmaxf(0.001f, dot(dd, dd)));                     // Light.cu:13
+    v3 lpos = wi.o;                                                         // Scene.cu:213
+    s.sr = spawn_ray(h, neg(wi.d));                                         // Scene.cu:218
+    v3 f = scale(rec_f(h, M, neg(wo_dir), s.sr.d), fabsf(dot(h.normal, s.sr.d)));   // Scene.cu:222
+    s.cast = !is_black(f);                                                  // Scene.cu:224
+    s.thr = length(sub(s.sr.o, lpos)) - 0.01f;                              // Scene.cu:227 rhs
+    // Scene.cu:233-241 with pdf_light = 1 (Light.cu:12), isDelta = true
+    s.contrib = is_black(color) ? mk3(0.0f, 0.0f, 0.0f) : divs(mul(color, f), 1.0f);
+    return s;
+}
+
+// ------------------------------------------------------------------ shade: spawn shadow rays
+// For every active path of the current bounce: draw the bounce's uniform4
+// (PathTracer.cu:27), classify hit / miss (PathTracer.cu:64), and for lights
+// [l0, l0 + nl) push one shadow ray per (hit, light) whose BRDF term is not black
+// (Scene.cu:224), compacted with wave ballots: a block reserves one contiguous
+// range of the shadow queue per pass, light-major inside each wave so that a wave
+// of the shadow pass holds neighbouring pixels towards the same light.
+__global__ __launch_bounds__(kBlock) void k_shade(DevView v, int cur, int bounce, int l0, int nl,
+                                                  int n_lights_total)
+{
+    __shared__ uint32_t s_tot[kWavesPerBlock];
+    __shared__ uint32_t s_base;
+    const uint32_t count = v.ctl->n_cur;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const RayQueue q = v.rays[cur];
+    for (uint32_t group = blockIdx.x; group * kBlock < count; group += gridDim.x) {
+        uint32_t chunk = group * kWavesPerBlock + wib;
+        uint32_t i = chunk * 64u + lane;
+        bool valid = i < count;
+        uint32_t p = 0;
+        Ray r;
+        r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0);
+        float t = kInf;
+        int32_t id = -1;
+        if (valid) {
+            p = q.path[i];
+            r.o = mk3(q.ox[i], q.oy[i], q.oz[i]);
+            r.d = mk3(q.dx[i], q.dy[i], q.dz[i]);
+            t = v.hit_t[i];
+            id = v.hit_id[i];
+        }
+        bool ishit = valid && scene_ishit(t) && id >= 0;
+        if (valid && l0 == 0) {
+            if (bounce == 0) {                       // id / t buffers of the primary hit
+                v.first_id[p] = id;
+                v.first_t[p] = t;
+            }
+            // draws of this bounce: tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
+            uint32_t draw = v.rng_ctr[p];
+            v.bounce_draw[p] = draw;
+            v.rng_ctr[p] = draw + 1u + (ishit ? (uint32_t)n_lights_total : 0u);
+            v.le[0][p] = 0.0f; v.le[1][p] = 0.0f; v.le[2][p] = 0.0f;
+            if (!ishit)                              // PathTracer.cu:64 -> return res
+                finalize_path(v, p, mk3(v.res[0][p], v.res[1][p], v.res[2][p]));
+        }
+        Hit h;
+        if (ishit)
+            fill_hit(v, r, id, h);
+        const ModelRec *M = ishit ? &v.models[h.model] : &v.models[0];
+
+        // pass 1: which lights cast a ray from this hit
+        uint64_t mask = 0;
+        uint32_t wave_total = 0;
+        for (int j = 0; j < nl; j++) {
+            bool cast = false;
+            if (ishit)
+                cast = sample_point_light(h, *M, r.d, v.lights[l0 + j]).cast;
+            uint64_t b = __ballot(cast);
+            if (cast)
+                mask |= (1ull << j);
+            wave_total += (uint32_t)__popcll(b);
+        }
+        // block-level reservation in the shadow queue
+        if (lane == 0)
+            s_tot[wib] = wave_total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < kWavesPerBlock; w++)
+                tot += s_tot[w];
+            s_base = tot ? atomicAdd(&v.ctl->n_shadow, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t base = s_base;
+        for (uint32_t w = 0; w < wib; w++)
+            base += s_tot[w];
+        __syncthreads();
+        if (valid) {
+            v.sh_mask[i] = mask;
+            if (lane == 0)
+                v.sh_base[chunk] = base;
+        }
+        // pass 2: write the entries, light-major within the wave
+        uint32_t off = base;
+        for (int j = 0; j < nl; j++) {
+            bool cast = (mask >> j) & 1ull;
+            uint64_t b = __ballot(cast);
+            if (cast) {
+                LightSample s = sample_point_light(h, *M, r.d, v.lights[l0 + j]);
+                uint32_t e = off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                RayQueue sq = v.shadow;
+                sq.ox[e] = s.sr.o.x; sq.oy[e] = s.sr.o.y; sq.oz[e] = s.sr.o.z;
+                sq.dx[e] = s.sr.d.x; sq.dy[e] = s.sr.d.y; sq.dz[e] = s.sr.d.z;
+                v.sh_thr[e] = s.thr;
+                v.sh_contrib[0][e] = s.contrib.x;
+                v.sh_contrib[1][e] = s.contrib.y;
+                v.sh_contrib[2][e] = s.contrib.z;
+            }
+            off += (uint32_t)__popcll(b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ finish the bounce
+// Same chunk <-> lane mapping as k_shade, so the ballots reproduce every entry's
+// slot.  Adds the unblocked contributions in light order (Scene.cu:120, 227-249),
+// then, after the last light pass, PathTracer.cu:73-88.
+__global__ __launch_bounds__(kBlock) void k_finish(DevView v, int cur, int bounce, int max_depth,
+                                                   int l0, int nl, int last_pass)
+{
+    __shared__ uint32_t s_tot[kWavesPerBlock];
+    __shared__ uint32_t s_base;
+    const uint32_t count = v.ctl->n_cur;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const RayQueue q = v.rays[cur];
+    const RayQueue qn = v.rays[cur ^ 1];
+    for (uint32_t group = blockIdx.x; group * kBlock < count; group += gridDim.x) {
+        uint32_t chunk = group * kWavesPerBlock + wib;
+        uint32_t i = chunk * 64u + lane;
+        bool valid = i < count;
+        uint32_t p = 0;
+        Ray r;
+        r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0);
+        float t = kInf;
+        int32_t id = -1;
+        uint64_t mask = 0;
+        if (valid) {
+            p = q.path[i];
+            r.o = mk3(q.ox[i], q.oy[i], q.oz[i]);
+            r.d = mk3(q.dx[i], q.dy[i], q.dz[i]);
+            t = v.hit_t[i];
+            id = v.hit_id[i];
+            mask = v.sh_mask[i];
+        }
+        bool ishit = valid && scene_ishit(t) && id >= 0;
+        uint32_t off = v.sh_base[valid ? chunk : 0];
+
+        // res += evaluateDirectLight(...) per light, in order (Scene.cu:120)
+        v3 le = mk3(0, 0, 0);
+        if (ishit)
+            le = mk3(v.le[0][p], v.le[1][p], v.le[2][p]);
+        for (int j = 0; j < nl; j++) {
+            bool cast = (mask >> j) & 1ull;
+            uint64_t b = __ballot(cast);
+            v3 c = mk3(0.0f, 0.0f, 0.0f);
+            if (cast) {
+                uint32_t e = off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+                float st = v.sh_hit_t[e];
+                int32_t sid = v.sh_hit_id[e];
+                bool blocked = false;
+                if (scene_ishit(st) && sid >= 0) {                       // Scene.cu:225
+                    Ray sr;
+                    sr.o = mk3(v.shadow.ox[e], v.shadow.oy[e], v.shadow.oz[e]);
+                    sr.d = mk3(v.shadow.dx[e], v.shadow.dy[e], v.shadow.dz[e]);
+                    v3 hp = sid < v.n_tris ? ray_pos(sr, st)
+                                           : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, st);
+                    // H3: `lightidx == idx` restated as never true for point lights
+                    blocked = length(sub(hp, sr.o)) < v.sh_thr[e];       // Scene.cu:227
+                }
+                if (!blocked)                                            // Scene.cu:236
+                    c = mk3(v.sh_contrib[0][e], v.sh_contrib[1][e], v.sh_contrib[2][e]);
+            }
+            if (ishit)
+                le = add(le, c);
+            off += (uint32_t)__popcll(b);
+        }
+
+        bool survive = false;
+        Ray nr;
+        nr.o = mk3(0, 0, 0); nr.d = mk3(0, 0, 0);
+        if (ishit && !last_pass) {
+            v.le[0][p] = le.x; v.le[1][p] = le.y; v.le[2][p] = le.z;
+        }
+        if (ishit && last_pass) {
+            v3 beta = mk3(v.beta[0][p], v.beta[1][p], v.beta[2][p]);
+            v3 res = mk3(v.res[0][p], v.res[1][p], v.res[2][p]);
+            res = add(res, mul(beta, le));                               // PathTracer.cu:73
+            Hit h;
+            fill_hit(v, r, id, h);
+            const ModelRec &M = v.models[h.model];
+            float u[4];
+            pixel_uniform4(v.pixmap[p], v.bounce_draw[p], u);            // tmp of PathTracer.cu:27
+            v3 wi;
+            float pdf;
+            v3 f = rec_sample_f(h, M, neg(r.d), wi, pdf, u[0], u[1]);    // PathTracer.cu:76
+            bool done = (pdf < 0.0001f || length(f) < 0.0001f);          // PathTracer.cu:77
+            if (!done) {
+                beta = mul(beta, divs(scale(f, fabsf(dot(wi, h.normal))), pdf));   // :79
+                nr = spawn_ray(h, wi);                                   // :80
+                if (bounce > 3) {                                        // :82-88
+                    if (u[2] < 0.5f)
+                        done = true;
+                    else
+                        beta = divs(beta, 1.0f - 0.5f);
+                }
+            }
+            if (!done && bounce + 1 > max_depth) {
+                // Next iteration: one draw (:27), a trace whose result nothing reads
+                // (Lambertian, no environment light), then the break of :64.
+                v.rng_ctr[p] = v.rng_ctr[p] + 1u;
+                done = true;
+            }
+            if (done) {
+                finalize_path(v, p, res);
+            } else {
+                survive = true;
+                v.beta[0][p] = beta.x; v.beta[1][p] = beta.y; v.beta[2][p] = beta.z;
+                v.res[0][p] = res.x; v.res[1][p] = res.y; v.res[2][p] = res.z;
+            }
+        }
+        if (!last_pass)
+            continue;                         // uniform: no barriers below are skipped unevenly
+        // compaction of the surviving paths into the next bounce's queue
+        uint64_t b = __ballot(survive);
+        if (lane == 0)
+            s_tot[wib] = (uint32_t)__popcll(b);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < kWavesPerBlock; w++)
+                tot += s_tot[w];
+            s_base = tot ? atomicAdd(&v.ctl->n_next, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t base = s_base;
+        for (uint32_t w = 0; w < wib; w++)
+            base += s_tot[w];
+        __syncthreads();
+        if (survive) {
+            uint32_t e = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            qn.ox[e] = nr.o.x; qn.oy[e] = nr.o.y; qn.oz[e] = nr.o.z;
+            qn.dx[e] = nr.d.x; qn.dy[e] = nr.d.y; qn.dz[e] = nr.d.z;
+            qn.path[e] = p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ readback helpers
+__global__ void k_scatter_image(const uint32_t *__restrict__ pixmap, uint32_t n,
+                                const float4 *__restrict__ fb, const int32_t *__restrict__ first_id,
+                                const float *__restrict__ first_t, float4 *rgba, int32_t *prim,
+                                float *t)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n)
+        return;
+    uint32_t pix = pixmap[p];
+    if (rgba) rgba[pix] = fb[p];
+    if (prim) prim[pix] = first_id[p];
+    if (t) t[pix] = first_t[p];
+}
+
+__global__ void k_fill_i32(int32_t *a, size_t n, int32_t value)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        a[i] = value;
+}
+
+// Scene::hit on caller rays: the Ray constructor's normalisation (Ray.cu:2), then
+// the same closest-hit kernel; this kernel only turns t into the returned bool.
+__global__ void k_prepare_rays(RayQueue q, const float *__restrict__ org,
+                               const float *__restrict__ dir, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    Ray r = make_ray(mk3(org[3 * i], org[3 * i + 1], org[3 * i + 2]),
+                     mk3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]));
+    q.ox[i] = r.o.x; q.oy[i] = r.o.y; q.oz[i] = r.o.z;
+    q.dx[i] = r.d.x; q.dy[i] = r.d.y; q.dz[i] = r.d.z;
+}
+__global__ void k_ishit(const float *__restrict__ t, int32_t *ishit, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        ishit[i] = scene_ishit(t[i]) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ post-process
+// HDRKernel (PostProcess/PostProcess.cuh:29-56): ACES filmic curve + saturate.
+__device__ __forceinline__ float aces1(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return fminf(1.0f, fmaxf(0.0f, (x * (a * x + b)) / (x * (c * x + d) + e)));
+}
+__global__ void k_tonemap(const float4 *__restrict__ in, float4 *__restrict__ out, uint32_t n)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    float4 c = in[i];
+    out[i] = make_float4(aces1(c.x), aces1(c.y), aces1(c.z), 1.0f);
+}
+// filterKernel (PostProcess.cuh:59-104): 3x3 window gathered x-major, the
+// reference's exchange sort by luma (descending), element count/2.
+__global__ void k_median3x3(const float4 *__restrict__ in, float4 *__restrict__ out, int width,
+                            int height)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height)
+        return;
+    float4 temp[9];
+    float ty[9];
+    int count = 0;
+    for (int i = x - 1; i <= x + 1; i++)
+        for (int j = y - 1; j <= y + 1; j++)
+            if (i >= 0 && i < width && j >= 0 && j < height) {
+                float4 c = in[(size_t)j * width + i];
+                temp[count] = c;
+                ty[count++] = 0.299f * c.x + 0.587f * c.y + 0.114f * c.z;
+            }
+    for (int i = 0; i < count; i++)
+        for (int j = 0; j < i; j++)
+            if (ty[i] > ty[j]) {
+                float sf = ty[i];
+                float4 s4 = temp[i];
+                ty[i] = ty[j];
+                temp[i] = temp[j];
+                ty[j] = sf;
+                temp[j] = s4;
+            }
+    out[(size_t)y * width + x] = temp[count / 2];
+}
+
+// ------------------------------------------------------------------ launchers
+static inline int grid_for(uint32_t n, int max_blocks)
+{
+    uint32_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if ((int)g > max_blocks) g = (uint32_t)max_blocks;
+    return (int)g;
+}
+
+void launch_ctl_begin(hipStream_t s, Ctl *ctl, uint32_t n) { k_ctl_begin<<<1, 1, 0, s>>>(ctl, n); }
+void launch_ctl_after_shadow(hipStream_t s, Ctl *ctl) { k_ctl_after_shadow<<<1, 1, 0, s>>>(ctl); }
+void launch_ctl_next_bounce(hipStream_t s, Ctl *ctl) { k_ctl_next_bounce<<<1, 1, 0, s>>>(ctl); }
+
+void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n)
+{
+    k_gen<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(v, p0, n);
+}
+
+void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
+                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks)
+{
+    k_intersect<<<grid_for(capacity, max_blocks), kBlock, 0, s>>>(
+        v.tris, v.n_tris, v.spheres, v.n_spheres, q, count, out_t, out_id);
+}
+
+void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
+                  int nl, int n_lights_total, int max_blocks)
+{
+    k_shade<<<grid_for(capacity, max_blocks), kBlock, 0, s>>>(v, cur, bounce, l0, nl,
+                                                              n_lights_total);
+}
+
+void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,
+                   int max_depth, int l0, int nl, int last_pass, int max_blocks)
+{
+    k_finish<<<grid_for(capacity, max_blocks), kBlock, 0, s>>>(v, cur, bounce, max_depth, l0, nl,
+                                                               last_pass);
+}
+
+void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,
+                          const int32_t *first_id, const float *first_t, float4 *rgba,
+                          int32_t *prim, float *t)
+{
+    if (n)
+        k_scatter_image<<<(n + 255) / 256, 256, 0, s>>>(pixmap, n, fb, first_id, first_t, rgba,
+                                                        prim, t);
+}
+
+void launch_fill_i32(hipStream_t s, int32_t *a, size_t n, int32_t value)
+{
+    if (n)
+        k_fill_i32<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(a, n, value);
+}
+
+void launch_prepare_rays(hipStream_t s, const RayQueue &q, const float *org, const float *dir,
+                         uint32_t n)
+{
+    if (n)
+        k_prepare_rays<<<(n + 255) / 256, 256, 0, s>>>(q, org, dir, n);
+}
+
+void launch_ishit(hipStream_t s, const float *t, int32_t *ishit, uint32_t n)
+{
+    if (n)
+        k_ishit<<<(n + 255) / 256, 256, 0, s>>>(t, ishit, n);
+}
+
+void launch_tonemap(hipStream_t s, const float4 *in, float4 *out, uint32_t n)
+{
+    if (n)
+        k_tonemap<<<(n + 255) / 256, 256, 0, s>>>(in, out, n);
+}
+
+void launch_median3x3(hipStream_t s, const float4 *in, float4 *out, int width, int height)
+{
+    dim3 b(16, 16), g((width + 15) / 16, (height + 15) / 16);
+    k_median3x3<<<g, b, 0, s>>>(in, out, width, height);
+}
+
+} // namespace rt

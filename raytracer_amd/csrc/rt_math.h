@@ -1,0 +1,196 @@
+// rt_math.h -- fp32 vector / mat4 arithmetic shared by the host-side upload code and
+// the gfx950 kernels.  Every function restates the operation ORDER of the reference
+// (helper_math.h, Matrix/Matrix.cu) so that values computed at upload time on the
+// host and values computed per ray on the GPU carry the same bits the reference's
+// per-ray code would produce.  Compile with -ffp-contract=off: no FMA contraction.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+struct v3 { float x, y, z; };
+struct v4 { float x, y, z, w; };
+struct m4 { float v[4][4]; };
+
+RT_HD v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD v4 mk4(float x, float y, float z, float w) { v4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+// helper_math.h:349, 579, 804, 814, 997 -- componentwise
+RT_HD v3 add(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD v3 sub(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD v3 mul(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD v3 scale(v3 a, float b) { return mk3(a.x * b, a.y * b, a.z * b); }
+RT_HD v3 divs(v3 a, float b) { return mk3(a.x / b, a.y / b, a.z / b); }
+RT_HD v3 neg(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+// helper_math.h:1248: (ax*bx + ay*by) + az*bz
+RT_HD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_HD float dot(v4 a, v4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+// helper_math.h:1420
+RT_HD v3 cross(v3 a, v3 b)
+{
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// helper_math.h:62-65: the oracle is the reference built as HOST code, where
+// rsqrtf(x) is 1.0f / sqrtf(x) (two correctly rounded operations).
+RT_HD float rsqrt_ref(float x) { return 1.0f / sqrtf(x); }
+RT_HD float length(v3 v) { return sqrtf(dot(v, v)); }                     // :1291
+RT_HD v3 normalize(v3 v) { float inv = rsqrt_ref(dot(v, v)); return scale(v, inv); }  // :1309
+RT_HD v4 normalize(v4 v)                                                  // :1314
+{
+    float inv = rsqrt_ref(dot(v, v));
+    return mk4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
+// Matrix/Matrix.cu:73-83
+RT_HD v4 apply4(const m4 &m, v4 a)
+{
+    v4 r;
+    r.x = m.v[0][0] * a.x + m.v[0][1] * a.y + m.v[0][2] * a.z + m.v[0][3] * a.w;
+    r.y = m.v[1][0] * a.x + m.v[1][1] * a.y + m.v[1][2] * a.z + m.v[1][3] * a.w;
+    r.z = m.v[2][0] * a.x + m.v[2][1] * a.y + m.v[2][2] * a.z + m.v[2][3] * a.w;
+    r.w = m.v[3][0] * a.x + m.v[3][1] * a.y + m.v[3][2] * a.z + m.v[3][3] * a.w;
+    return r;
+}
+// Matrix/Matrix.cu:85-91: homogeneous point, divided by w
+RT_HD v3 apply3(const m4 &m, v3 a)
+{
+    v4 r = apply4(m, mk4(a.x, a.y, a.z, 1.0f));
+    return mk3(r.x / r.w, r.y / r.w, r.z / r.w);
+}
+// direction: make_float3(M(make_float4(v, 0)))
+RT_HD v3 apply_dir(const m4 &m, v3 a)
+{
+    v4 r = apply4(m, mk4(a.x, a.y, a.z, 0.0f));
+    return mk3(r.x, r.y, r.z);
+}
+// Matrix/Matrix.cu:235-243
+RT_HD m4 transpose(const m4 &m)
+{
+    m4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            r.v[i][j] = m.v[j][i];
+    return r;
+}
+// Matrix/Matrix.cu:181-233 -- cofactors, scale by 1/det, transpose.  The
+// reference's factor11 repeats factor07's expression; kept.
+RT_HD m4 inverse(const m4 &mm)
+{
+    const float(*m)[4] = mm.v;
+    float f00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+    float f01 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    float f02 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+    float f03 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    float f04 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+    float f05 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    float f06 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+    float f07 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float f08 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+    float f09 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+    float f10 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+    float f11 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float f12 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+    float f13 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    float f14 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    float f15 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    float f16 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    float f17 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    float f18 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+
+    m4 I;
+    I.v[0][0] = +(m[1][1] * f00 - m[1][2] * f01 + m[1][3] * f02);
+    I.v[0][1] = -(m[1][0] * f00 - m[1][2] * f03 + m[1][3] * f04);
+    I.v[0][2] = +(m[1][0] * f01 - m[1][1] * f03 + m[1][3] * f05);
+    I.v[0][3] = -(m[1][0] * f02 - m[1][1] * f04 + m[1][2] * f05);
+
+    I.v[1][0] = -(m[0][1] * f00 - m[0][2] * f01 + m[0][3] * f02);
+    I.v[1][1] = +(m[0][0] * f00 - m[0][2] * f03 + m[0][3] * f04);
+    I.v[1][2] = -(m[0][0] * f01 - m[0][1] * f03 + m[0][3] * f05);
+    I.v[1][3] = +(m[0][0] * f02 - m[0][1] * f04 + m[0][2] * f05);
+
+    I.v[2][0] = +(m[0][1] * f06 - m[0][2] * f07 + m[0][3] * f08);
+    I.v[2][1] = -(m[0][0] * f06 - m[0][2] * f09 + m[0][3] * f10);
+    I.v[2][2] = +(m[0][0] * f11 - m[0][1] * f09 + m[0][3] * f12);
+    I.v[2][3] = -(m[0][0] * f08 - m[0][1] * f10 + m[0][2] * f12);
+
+    I.v[3][0] = -(m[0][1] * f13 - m[0][2] * f14 + m[0][3] * f15);
+    I.v[3][1] = +(m[0][0] * f13 - m[0][2] * f16 + m[0][3] * f17);
+    I.v[3][2] = -(m[0][0] * f14 - m[0][1] * f16 + m[0][3] * f18);
+    I.v[3][3] = +(m[0][0] * f15 - m[0][1] * f17 + m[0][2] * f18);
+
+    float det = +m[0][0] * I.v[0][0] + m[0][1] * I.v[0][1] + m[0][2] * I.v[0][2] +
+                m[0][3] * I.v[0][3];
+    float b = 1.0f / det;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            I.v[i][j] *= b;
+    return transpose(I);
+}
+
+// ---- constants of the path (reference file:line) ----
+constexpr float kInf = 1000000.0f;          // Ray/IntersectionRecord.cuh:7-9  INF
+constexpr float kEps = 1e-2f;               // Model/Model.cuh:24-26           FLOAT_EPISLON
+constexpr float kInvPi = 0.318309892f;      // Material/material.cu:5
+constexpr float kPiOver4 = 0.78539816339744830961f;  // material.cu:7
+constexpr float kPiOver2 = 1.57079632679489661923f;  // material.cu:8
+constexpr int kMatLambertian = 1;           // Material/Object.cuh:15
+constexpr int kMatSpecularBit = 4;          // Material/Object.cuh:10
+
+// ---- device-resident scene records (built on the host at upload) ----
+// One 64-byte record per triangle, in the reference's traversal order.  Every
+// field is a ray-independent sub-expression of Triangle::hit (Model/Model.cu:91-137)
+// evaluated with the reference's own operation order:
+//   a,b,c = transformation(pos[i])             (:94, Matrix.cu:85-91)
+//   n     = cross(a - c, b - c)                (:97)
+//   dn    = dot(a, n)                          (:102, second term)
+//   S     = 2.0f * area()                      (:106, :413-420)
+struct TriRec {
+    float ax, ay, az, dn;
+    float bx, by, bz, S;
+    float cx, cy, cz, pad0;
+    float nx, ny, nz, pad1;
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+// Read only for the winning triangle (Model.cu:122-131).
+struct TriCold {
+    float n0[3], n1[3], n2[3];   // Triangle::normal[3]
+    int32_t model;
+    int32_t pad[2];
+};
+static_assert(sizeof(TriCold) == 48, "TriCold must be 48 bytes");
+
+struct ModelRec {
+    m4 cas;             // transpose(inverse(transformation)), Model.cu:126
+    float color[3];     // Lambertian::color
+    int32_t mat_type;   // material::MATERIAL_TYPE
+};
+
+struct SphereRec {
+    m4 M;               // transformation
+    m4 inv;             // inverse(transformation), Model.cu:352
+    float rad;          // getRadius() = 1 / coefficient.x, Model.cu:341-346
+    float rad2;         // getRadius() * getRadius(), Model.cu:364
+    int32_t model;
+    int32_t type;       // quadraticType; only Sphere (0) intersects
+};
+
+struct LightRec { float pos[3]; float illum[3]; };
+
+// Camera after its constructor (Camera/Camera.cu:4-14); pers/raster2world are dead.
+struct CameraRec {
+    v3 pos, up, front, right;
+    int32_t res_x, res_y;
+    float n;
+};
+
+} // namespace rt

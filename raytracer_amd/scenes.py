@@ -1,0 +1,277 @@
+"""Seeded synthetic scenes for the five BASELINE.json configs.
+
+The real Stanford meshes are not in the container, so C3/C4 use seeded displaced-sphere
+meshes with the SAME triangle counts (69 451 / 871 414) and C5 a 10 000 000-triangle
+height field.  Meshes are built at the scale hazard H1 demands (typical 2*area >> 0.01,
+because Triangle::hit uses absolute tolerances, Model/Model.cu:99,113).  All surfaces are
+Lambertian, albedo 0.7.  Every generator is deterministic (numpy default_rng(seed)).
+
+Meshes can be written as OBJ (v / vn / f a//c, triangles only -- what Mesh::readFile,
+Model/Model.cu:139-284, accepts, hazard H6) so tests can push them through the loader.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .scene import CameraArgs, SceneBuilder, SceneData, identity, scale, translation
+
+ALBEDO = (0.7, 0.7, 0.7)
+
+
+@dataclass
+class Config:
+    name: str
+    scene: SceneData
+    camera: CameraArgs
+    width: int
+    height: int
+    spp: int
+    description: str
+
+
+# ----------------------------------------------------------------------------- meshes
+def _quad(a, b, c, d, n):
+    """two triangles (a,b,c), (a,c,d) with a constant normal n."""
+    pos = np.array([[a, b, c], [a, c, d]], np.float32)
+    nrm = np.broadcast_to(np.asarray(n, np.float32), (2, 3, 3)).copy()
+    return pos, nrm
+
+
+def _box(lo, hi):
+    """12 outward-facing triangles of an axis-aligned box."""
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    P, N = [], []
+    faces = [
+        ((x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1), (0, 0, 1)),
+        ((x1, y0, z0), (x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (0, 0, -1)),
+        ((x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0), (-1, 0, 0)),
+        ((x1, y0, z1), (x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (1, 0, 0)),
+        ((x0, y1, z1), (x1, y1, z1), (x1, y1, z0), (x0, y1, z0), (0, 1, 0)),
+        ((x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1), (0, -1, 0)),
+    ]
+    for a, b, c, d, n in faces:
+        p, q = _quad(a, b, c, d, n)
+        P.append(p)
+        N.append(q)
+    return np.concatenate(P), np.concatenate(N)
+
+
+def cornell_mesh():
+    """36 triangles: 5 walls x 2, two boxes x 12, ceiling-light quad x 2 (plain Lambertian)."""
+    X, Y, Z0, Z1 = 24.5, 13.75, -40.0, -68.0
+    P, N = [], []
+    walls = [
+        ((-X, -Y, Z0), (X, -Y, Z0), (X, -Y, Z1), (-X, -Y, Z1), (0, 1, 0)),     # floor
+        ((-X, Y, Z0), (-X, Y, Z1), (X, Y, Z1), (X, Y, Z0), (0, -1, 0)),        # ceiling
+        ((-X, -Y, Z1), (X, -Y, Z1), (X, Y, Z1), (-X, Y, Z1), (0, 0, 1)),       # back
+        ((-X, -Y, Z0), (-X, -Y, Z1), (-X, Y, Z1), (-X, Y, Z0), (1, 0, 0)),     # left
+        ((X, -Y, Z0), (X, Y, Z0), (X, Y, Z1), (X, -Y, Z1), (-1, 0, 0)),        # right
+    ]
+    for a, b, c, d, n in walls:
+        p, q = _quad(a, b, c, d, n)
+        P.append(p)
+        N.append(q)
+    for lo, hi in [((-15.0, -Y, -50.0), (-6.0, -Y + 8.25, -43.0)),             # short box
+                   ((4.0, -Y, -62.5), (13.0, -Y + 16.5, -53.5))]:              # tall box
+        p, q = _box(lo, hi)
+        P.append(p)
+        N.append(q)
+    p, q = _quad((-3.25, Y - 0.05, -51.5), (3.25, Y - 0.05, -51.5), (3.25, Y - 0.05, -56.75),
+                 (-3.25, Y - 0.05, -56.75), (0, -1, 0))                        # light quad
+    P.append(p)
+    N.append(q)
+    pos, nrm = np.concatenate(P), np.concatenate(N)
+    assert pos.shape[0] == 36
+    return pos, nrm
+
+
+def blob_mesh(n_lon, n_lat, radius, seed, bump=0.18):
+    """Displaced lat-long sphere: 2 * n_lon * n_lat triangles, seeded low-frequency bumps.
+    The polar caps are left open (tiny holes) so that no triangle is degenerate."""
+    rng = np.random.default_rng(seed)
+    k = 6
+    freq = rng.integers(1, 6, size=(k, 2)).astype(np.float64)
+    phase = rng.uniform(0, 2 * np.pi, size=(k, 2))
+    amp = rng.uniform(0.3, 1.0, size=k)
+    amp *= bump / amp.sum()
+    eps = 0.02
+    th = np.linspace(eps, np.pi - eps, n_lat + 1)
+    ph = np.linspace(0.0, 2 * np.pi, n_lon + 1)
+    TH, PH = np.meshgrid(th, ph, indexing="ij")
+    r = np.ones_like(TH)
+    for i in range(k):
+        r += amp[i] * np.sin(freq[i, 0] * TH * 2 + phase[i, 0]) * np.cos(freq[i, 1] * PH + phase[i, 1])
+    r[:, -1] = r[:, 0]                       # close the seam exactly
+    r *= radius
+    V = np.stack([r * np.sin(TH) * np.cos(PH), r * np.cos(TH), r * np.sin(TH) * np.sin(PH)], -1)
+    V[:, -1] = V[:, 0]
+    Nn = V / np.linalg.norm(V, axis=-1, keepdims=True)
+    a, b, c, d = V[:-1, :-1], V[1:, :-1], V[1:, 1:], V[:-1, 1:]
+    na, nb, nc, nd = Nn[:-1, :-1], Nn[1:, :-1], Nn[1:, 1:], Nn[:-1, 1:]
+    pos = np.stack([np.stack([a, b, c], -2), np.stack([a, c, d], -2)], 2).reshape(-1, 3, 3)
+    nrm = np.stack([np.stack([na, nb, nc], -2), np.stack([na, nc, nd], -2)], 2).reshape(-1, 3, 3)
+    return pos.astype(np.float32), nrm.astype(np.float32)
+
+
+def grid_mesh(nx, nz, x0, x1, z0, z1, y, seed=None, amp=0.0):
+    """Height field over [x0,x1] x [z0,z1]: 2 * nx * nz triangles, central-difference normals."""
+    xs = np.linspace(x0, x1, nx + 1)
+    zs = np.linspace(z0, z1, nz + 1)
+    Z, X = np.meshgrid(zs, xs, indexing="ij")
+    Yh = np.full_like(X, y, dtype=np.float64)
+    if amp:
+        rng = np.random.default_rng(seed)
+        for _ in range(5):
+            fx, fz = rng.uniform(2, 9, 2)
+            px, pz = rng.uniform(0, 2 * np.pi, 2)
+            Yh += amp / 5 * np.sin(fx * (X - x0) / (x1 - x0) * 2 * np.pi + px) * \
+                np.cos(fz * (Z - z0) / (z1 - z0) * 2 * np.pi + pz)
+    V = np.stack([X, Yh, Z], -1)
+    gy_z, gy_x = np.gradient(Yh, zs, xs)
+    Nn = np.stack([-gy_x, np.ones_like(Yh), -gy_z], -1)
+    Nn /= np.linalg.norm(Nn, axis=-1, keepdims=True)
+    a, b, c, d = V[:-1, :-1], V[1:, :-1], V[1:, 1:], V[:-1, 1:]
+    na, nb, nc, nd = Nn[:-1, :-1], Nn[1:, :-1], Nn[1:, 1:], Nn[:-1, 1:]
+    pos = np.stack([np.stack([a, b, c], -2), np.stack([a, c, d], -2)], 2).reshape(-1, 3, 3)
+    nrm = np.stack([np.stack([na, nb, nc], -2), np.stack([na, nc, nd], -2)], 2).reshape(-1, 3, 3)
+    return pos.astype(np.float32), nrm.astype(np.float32)
+
+
+def write_obj(path, pos, nrm):
+    """v / vn / f a//a, triangles only: what Mesh::readFile parses (Model.cu:150-206).
+    %.9g round-trips float32 exactly."""
+    pos = np.asarray(pos, np.float32).reshape(-1, 3)
+    nrm = np.asarray(nrm, np.float32).reshape(-1, 3)
+    with open(path, "w") as f:
+        f.write("# seeded synthetic mesh (raytracer_amd.scenes)\n")
+        for v in pos:
+            f.write("v %.9g %.9g %.9g\n" % tuple(v))
+        for v in nrm:
+            f.write("vn %.9g %.9g %.9g\n" % tuple(v))
+        for i in range(pos.shape[0] // 3):
+            a = 3 * i + 1
+            f.write(f"f {a}//{a} {a + 1}//{a + 1} {a + 2}//{a + 2}\n")
+
+
+# ----------------------------------------------------------------------------- configs
+def c1(width=640, height=480):
+    """Single sphere + 1 point light: the reference's own test scene values
+    (kernel.cu:285-291, 301; camera kernel.cu:228-229)."""
+    b = SceneBuilder()
+    b.add_sphere(0.33, translation(0.0, 0.0, -8.0), color=ALBEDO)
+    b.add_point_light((-8.0, 0.0, 0.0), (233.7, 33.8, 77.7))
+    return Config("c1", b.build(), CameraArgs.for_image(width, height), width, height, 1,
+                  "single sphere + 1 point light, 640x480, 1 spp")
+
+
+def c2(width=1920, height=1080):
+    pos, nrm = cornell_mesh()
+    b = SceneBuilder()
+    b.add_mesh(pos, nrm, identity(), ALBEDO)
+    b.add_point_light((-7.5, 10.0, -50.0), (550.0, 500.0, 400.0))
+    b.add_point_light((8.5, 9.0, -47.5), (300.0, 350.0, 450.0))
+    cam = CameraArgs.for_image(width, height, near=1.0)
+    return Config("c2", b.build(), cam, width, height, 16,
+                  "Cornell box (36 tris), 2 point lights, 1920x1080, 16 spp")
+
+
+def _blob_scene(n_lon, n_lat, radius, ground, backdrop, seed, lights):
+    pos, nrm = blob_mesh(n_lon, n_lat, radius, seed)
+    z = -4.2 * radius
+    b = SceneBuilder()
+    if backdrop:
+        # one standalone Triangle model (Scene.cu:17-23), kept small: hazard H1 cuts both ways,
+        # 2*area beyond a few thousand drowns the 0.001 tolerance of Model.cu:113 in fp32 noise
+        R = 0.3 * radius
+        b.add_triangle([(-2.2 * radius - R, -1.2 * radius, z), (-2.2 * radius + R, -1.2 * radius, z),
+                        (-2.2 * radius, -1.2 * radius + 1.6 * R, z)], [(0, 0, 1)] * 3, identity(),
+                       ALBEDO)
+    # The mesh is placed by moving its vertices, with an identity transformation: the
+    # reference normalises the transformed normal as a float4 (Model.cu:127), so any
+    # translation in Model::transformation leaks into w and shrinks the shading normal.
+    pos = pos + np.array([0.0, 0.0, z], np.float32)
+    b.add_mesh(pos, nrm, identity(), ALBEDO)
+    gx, gz = ground
+    gp, gn = grid_mesh(gx, gz, -3.0 * radius, 3.0 * radius, z - 2.5 * radius, z + 2.0 * radius,
+                       -1.2 * radius)
+    b.add_mesh(gp, gn, identity(), ALBEDO)
+    for p, i in lights:
+        b.add_point_light(p, i)
+    return b.build()
+
+
+def c3(width=1920, height=1080, lon=180, lat=180, ground=(75, 31)):
+    """'Stanford bunny' stand-in: 2*180*180 + 2*75*31 + 1 = 69 451 triangles, 3 lights."""
+    R = 125.0
+    k = R * R * 16.0
+    lights = [((-3.0 * R, 3.0 * R, -1.5 * R), (3.0 * k, 2.6 * k, 2.2 * k)),
+              ((3.5 * R, 2.0 * R, -2.0 * R), (1.2 * k, 1.5 * k, 2.0 * k)),
+              ((0.0, 4.0 * R, -6.0 * R), (1.5 * k, 1.5 * k, 1.5 * k))]
+    s = _blob_scene(lon, lat, R, ground, True, 20240603, lights)
+    cam = CameraArgs.for_image(width, height, near=0.6)
+    return Config("c3", s, cam, width, height, 64,
+                  f"displaced-sphere 'bunny' ({s.n_tris} tris), 3 point lights, 1920x1080, 64 spp")
+
+
+def c4(width=3840, height=2160, lon=660, lat=660, ground=(107, 1)):
+    """'Stanford dragon' stand-in: 2*660*660 + 2*107*1 = 871 414 triangles, C3's 3 lights."""
+    R = 450.0
+    k = R * R * 16.0
+    lights = [((-3.0 * R, 3.0 * R, -1.5 * R), (3.0 * k, 2.6 * k, 2.2 * k)),
+              ((3.5 * R, 2.0 * R, -2.0 * R), (1.2 * k, 1.5 * k, 2.0 * k)),
+              ((0.0, 4.0 * R, -6.0 * R), (1.5 * k, 1.5 * k, 1.5 * k))]
+    s = _blob_scene(lon, lat, R, ground, False, 20240604, lights)
+    cam = CameraArgs.for_image(width, height, near=0.6)
+    return Config("c4", s, cam, width, height, 256,
+                  f"displaced-sphere 'dragon' ({s.n_tris} tris), 3 point lights, 3840x2160, 256 spp")
+
+
+def c5(width=3840, height=2160, nx=2500, nz=2000, n_light_side=8):
+    """Synthetic height field: 2*2500*2000 = 10 000 000 triangles, 64 point lights (8x8)."""
+    span = 3000.0
+    pos, nrm = grid_mesh(nx, nz, -span / 2, span / 2, -400.0 - span * 0.8, -400.0, -260.0,
+                         seed=12345, amp=90.0)
+    b = SceneBuilder()
+    b.add_mesh(pos, nrm, identity(), ALBEDO)
+    rng = np.random.default_rng(12345)
+    k = 2.0e5 * 64.0 / (n_light_side * n_light_side)
+    for i in range(n_light_side):
+        for j in range(n_light_side):
+            x = -span / 2 + span * (i + 0.5) / n_light_side
+            z = -400.0 - span * 0.8 * (j + 0.5) / n_light_side
+            col = k * rng.uniform(0.6, 1.0, 3)
+            b.add_point_light((x, 260.0, z), tuple(col))
+    cam = CameraArgs.for_image(width, height, near=0.6, pos=(0.0, 120.0, 0.0),
+                               lookat=(0.0, 0.0, -1000.0))
+    s = b.build()
+    return Config("c5", s, cam, width, height, 64,
+                  f"height field ({s.n_tris} tris), {s.n_lights} point lights, 3840x2160, 64 spp")
+
+
+def mixed_test_scene(seed=7):
+    """Small scene that touches every branch of the path: standalone triangles, two meshes
+    with non-trivial transforms, two spheres, three lights (one casting long shadows)."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    b.add_triangle([(-400, -120, -900), (400, -120, -900), (0, 500, -900)], [(0, 0, 1)] * 3,
+                   identity(), (0.7, 0.6, 0.5))
+    b.add_triangle([(-60, -20, -300), (10, -25, -310), (-20, 50, -290)],
+                   [(0.1, 0.0, 1.0), (0.0, 0.1, 1.0), (-0.1, 0.0, 1.0)], translation(15, 5, -40),
+                   (0.2, 0.7, 0.3))
+    p, n = blob_mesh(14, 10, 1.0, seed)
+    xf = translation(60.0, 10.0, -420.0) @ scale(55.0, 45.0, 50.0)
+    b.add_mesh(p, n, xf.astype(np.float32), (0.7, 0.7, 0.7))
+    gp, gn = grid_mesh(9, 7, -300, 300, -800, -150, -110.0, seed=seed, amp=25.0)
+    b.add_mesh(gp, gn, identity(), (0.6, 0.6, 0.7))
+    b.add_sphere(1.0 / 40.0, translation(-110.0, -40.0, -380.0), (0.7, 0.2, 0.1))
+    b.add_sphere(1.0 / 25.0, translation(20.0, -70.0, -260.0), (0.3, 0.3, 0.8))
+    b.add_point_light((-300.0, 300.0, -100.0), (3.0e5, 2.5e5, 2.0e5))
+    b.add_point_light((250.0, 150.0, -200.0), (1.0e5, 1.5e5, 2.0e5))
+    b.add_point_light((0.0, 20.0, -600.0), (0.8e5, 0.8e5, 0.8e5))
+    return b.build(), rng
+
+
+CONFIGS = {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s (primary + shadow rays actually cast) of the render path on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the workload: `spp` progressive samples of the
+whole frame at max_depth = 0 (rays = primary + shadow), with the
+scene resident in HBM.  With N > 1 the frame is tile-partitioned over the ranks (64x64
+tiles, round-robin; scene replicated) and the step ends with the RCCL gather of the
+partition framebuffers -- total work is fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_intersect, the
+brute-force closest hit): algorithmic bytes per launch / its mean HIP-event duration,
+against the 8 TB/s HBM peak.  `cpu_baseline` is the CPU oracle (a port of the reference's
+per-pixel code) timed on this box's host cores on a bounded crop of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3     # vector fp32 peak (counts an FMA as 2 flops)
+TRI_BYTES = 36.0             # 9 floats of positions per triangle
+SPH_BYTES = 132.0            # mat4 + inverse + radius
+RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
+RAY_IO_BYTES = 32.0          # 24 B ray in + 8 B (t, id) out per ray
+FLOPS_PER_TEST = 86.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--spp", type=int, default=0, help="samples per step (default: the config's)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-crop", type=int, nargs=2, default=None, metavar=("W", "H"))
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, spp, crop_wh):
+    """Oracle on host cores, bounded sample (rank 0, N = 1 only)."""
+    from tests import orc
+    cw, ch = crop_wh
+    cw, ch = min(cw, cfg.width), min(ch, cfg.height)
+    x0, y0 = (cfg.width - cw) // 2, (cfg.height - ch) // 2
+    threads = min(orc.lib().orc_num_threads(), 16)
+    t0 = time.perf_counter()
+    r = orc.render(cfg.scene, cfg.camera, cfg.width, cfg.height, spp=spp, max_depth=0,
+                   crop=(x0, y0, x0 + cw, y0 + ch), threads=threads)
+    dt = time.perf_counter() - t0
+    rays = r["primary"] + r["shadow"]
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"oracle, centre crop {cw}x{ch} of {cfg.width}x{cfg.height}, {spp} spp, "
+                      f"max_depth 0, {rays} rays in {dt:.2f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+    from raytracer_amd import abi, scenes
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    kw = {}
+    if a.width and a.height:
+        kw = dict(width=a.width, height=a.height)
+    cfg = scenes.CONFIGS[a.config](**kw)
+    spp = a.spp or cfg.spp
+
+    ctx = abi.Context(cfg.width, cfg.height, dev)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    ctx.set_partition(rank, world, 64)
+    n_local = ctx.local_pixel_count()
+
+    gather_in = gather_out = None
+    if world > 1:
+        counts = [None] * world
+        dist.all_gather_object(counts, n_local)
+        n_max = max(counts)
+        gather_in = torch.zeros((n_max, 4), dtype=torch.float32, device="cuda")
+        gather_out = torch.zeros((world * n_max, 4), dtype=torch.float32, device="cuda")
+
+    def step():
+        ctx.reset()                      # a fresh frame: counters, RNG streams, framebuffer
+        ctx.render(spp, 0)
+        if world > 1:                    # final framebuffer gathered over xGMI (RCCL)
+            ctx.export_local_rgba(gather_in.data_ptr())
+            dist.all_gather_into_tensor(gather_out, gather_in)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.reset_stats()
+    ctx.set_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_timing(False)
+
+    rays_local = float(st.primary_rays + st.shadow_rays)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        rr = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        rays_total = float(rr.item())
+    else:
+        rays_total = rays_local
+
+    if rank == 0:
+        sc = cfg.scene
+        n_tri, n_sph = sc.n_tris, sc.n_quads
+        # dominant kernel: closest hit.  Units of one launch = rays; per-unit figure below.
+        rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
+        launches = max(1, st.intersect_launches)
+        per_ray_bytes = (n_tri * TRI_BYTES + n_sph * SPH_BYTES) / RAYS_PER_FETCH + RAY_IO_BYTES
+        k_ms = st.intersect_ms / launches
+        bytes_per_launch = per_ray_bytes * rays_k / launches
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        tests = rays_k * (n_tri + n_sph)
+        flops = tests * FLOPS_PER_TEST
+        out = {
+            "metric": "Mrays/sec (primary+shadow) at 1080p",
+            "value": rays_total / dt / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {cfg.description}", "width": cfg.width,
+                       "height": cfg.height, "spp_per_step": spp, "max_depth": 0,
+                       "triangles": n_tri, "spheres": n_sph, "lights": sc.n_lights,
+                       "partition": f"64x64 tiles round-robin over {world} GPU(s)",
+                       "rays_per_step": rays_total / a.steps},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_intersect", "avg_launch_ms": k_ms,
+                         "launches_timed": int(launches),
+                         "bytes_per_launch": bytes_per_launch,
+                         "note": "brute-force all-pairs scan is VALU-bound by construction "
+                                 "(SURVEY 8(d)); see `valu`"},
+            "valu": {"tests_per_s": tests / (st.intersect_ms * 1e-3) if st.intersect_ms else 0.0,
+                     "algorithmic_tflops": flops / (st.intersect_ms * 1e-3) / 1e12
+                     if st.intersect_ms else 0.0,
+                     "peak_tflops": FP32_PEAK_TFLOPS,
+                     "frac": (flops / (st.intersect_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS)
+                     if st.intersect_ms else 0.0,
+                     "intersect_share_of_step": st.intersect_ms / (st.render_ms or 1.0)},
+        }
+        if world == 1 and not a.no_cpu:
+            crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (512, 288),
+                                                         "c3": (48, 27), "c4": (12, 8),
+                                                         "c5": (4, 2)}[cfg.name]
+            cpu_spp = spp if cfg.name in ("c1", "c2") else 1
+            out["cpu_baseline"] = cpu_baseline(cfg, cpu_spp, crop)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

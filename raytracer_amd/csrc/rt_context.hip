@@ -47,7 +47,7 @@ struct rt_context {
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
 
     // stats
-    uint64_t samples = 0, primary = 0, launches = 0;
+    uint64_t samples = 0, primary = 0, launches = 0, timed_launches = 0;
     double intersect_ms = 0.0, render_ms = 0.0;
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -214,6 +214,19 @@ hipEvent_t next_event(rt_context *c)
     return c->ev_pool[c->ev_used++];
 }
 
+// Sum the recorded (start, stop) pairs; the stream must be idle.
+void resolve_events(rt_context *c)
+{
+    for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess) {
+            c->intersect_ms += ms;
+            c->timed_launches++;
+        }
+    }
+    c->ev_used = 0;
+}
+
 // One closest-hit launch, optionally bracketed by HIP events on the launch stream.
 void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, uint32_t cap,
                      float *out_t, int32_t *out_id)
@@ -378,7 +391,6 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     for (int smp = 0; smp < n_samples; smp++) {
         c->cnt++;
         v.cnt = c->cnt;
-        c->ev_used = 0;
         for (uint32_t p0 = 0; p0 < c->n_local; p0 += c->batch) {
             const uint32_t n = std::min(c->batch, c->n_local - p0);
             launch_ctl_begin(s, v.ctl, n);
@@ -403,18 +415,17 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             c->primary += n;
         }
         c->samples += c->n_local;
-        if (c->timing) {
+        // event pairs are resolved without disturbing the stream: only when the pool
+        // would grow past a bound, or at the end of the call (which synchronises anyway)
+        if (c->timing && c->ev_used > 32768) {
             RT_HIP(c, hipStreamSynchronize(s));
-            for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess)
-                    c->intersect_ms += ms;
-            }
+            resolve_events(c);
         }
     }
     RT_HIP(c, hipEventRecord(c->ev_r1, s));
     RT_HIP(c, hipStreamSynchronize(s));          // cudaStreamSynchronize, kernel.cu:123
     RT_HIP(c, hipGetLastError());
+    resolve_events(c);
     float ms = 0.0f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->ev_r0, c->ev_r1));
     c->render_ms += ms;
@@ -563,7 +574,7 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->primary_rays = c->primary;
     st->shadow_rays = h.shadow_total;
     st->bounce_rays = h.bounce_total;
-    st->intersect_launches = c->launches;
+    st->intersect_launches = c->timing ? c->timed_launches : c->launches;
     st->intersect_ms = c->intersect_ms;
     st->render_ms = c->render_ms;
     st->n_prims = c->n_prims;
@@ -576,7 +587,7 @@ extern "C" int rt_reset_stats(rt_context *c)
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemset(c->v.ctl, 0, sizeof(Ctl)));
-    c->samples = c->primary = c->launches = 0;
+    c->samples = c->primary = c->launches = c->timed_launches = 0;
     c->intersect_ms = c->render_ms = 0.0;
     return RT_OK;
 }

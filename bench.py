@@ -98,20 +98,17 @@ def main():
     ctx.set_partition(rank, world, 64)
     n_local = ctx.local_pixel_count()
 
-    gather_in = gather_out = None
+    gather = None
     if world > 1:
-        counts = [None] * world
-        dist.all_gather_object(counts, n_local)
-        n_max = max(counts)
-        gather_in = torch.zeros((n_max, 4), dtype=torch.float32, device="cuda")
-        gather_out = torch.zeros((world * n_max, 4), dtype=torch.float32, device="cuda")
+        from raytracer_amd.dist import FrameGather
+        gather = FrameGather(cfg.width, cfg.height, world, 64, "cuda", abi.partition_pixels)
 
     def step():
         ctx.reset()                      # a fresh frame: counters, RNG streams, framebuffer
         ctx.render(spp, 0)
         if world > 1:                    # final framebuffer gathered over xGMI (RCCL)
-            ctx.export_local_rgba(gather_in.data_ptr())
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            ctx.export_local_rgba(gather.local.data_ptr())
+            gather.gather(dist)
 
     def fence():
         if world > 1:

@@ -104,6 +104,12 @@ int rt_set_camera(rt_context *ctx, const rt_camera_desc *cam);
  * Default: rank 0 of 1, tile 64.  Resets the accumulation. */
 int rt_set_partition(rt_context *ctx, int rank, int world, int tile);
 
+/* The partition as a pure host computation (no device needed): the global pixel
+ * indices (y*W + x) rank `rank` of `world` owns, in the order its local buffers use.
+ * indices may be NULL to query the count only. */
+int rt_partition_pixels(int width, int height, int rank, int world, int tile, int32_t *indices,
+                        int64_t *count);
+
 /* Zero the framebuffer, the frame counter and restart every RNG stream
  * (what re-running initCUDA does in the reference). */
 int rt_reset(rt_context *ctx);

@@ -21,7 +21,7 @@ INF = np.float32(1000000.0)
 
 # every symbol include/rt_abi.h declares
 ABI_SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_set_partition", "rt_reset",
+    "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_set_partition", "rt_partition_pixels", "rt_reset",
     "rt_render", "rt_read_framebuffer", "rt_local_pixel_count", "rt_local_pixel_indices",
     "rt_export_local_rgba", "rt_scene_hit", "rt_postprocess", "rt_get_stats", "rt_reset_stats",
     "rt_set_timing", "rt_last_error", "rt_obj_load", "rt_obj_free", "rt_write_ppm", "rt_write_pfm",
@@ -57,6 +57,7 @@ def lib():
         L.rt_upload_scene.argtypes = [VP, C.POINTER(SceneDesc)]
         L.rt_set_camera.argtypes = [VP, C.POINTER(CameraDesc)]
         L.rt_set_partition.argtypes = [VP, C.c_int, C.c_int, C.c_int]
+        L.rt_partition_pixels.argtypes = [C.c_int] * 5 + [IP, C.POINTER(C.c_int64)]
         L.rt_reset.argtypes = [VP]
         L.rt_render.argtypes = [VP, C.c_int, C.c_int]
         L.rt_read_framebuffer.argtypes = [VP, FP, IP, FP]
@@ -190,6 +191,19 @@ class Context:
 
     def set_timing(self, enabled=True):
         self._chk(lib().rt_set_timing(self._h, 1 if enabled else 0))
+
+
+def partition_pixels(width, height, rank, world, tile=64):
+    """Global pixel indices owned by `rank` of `world` (host-only)."""
+    n = C.c_int64()
+    rc = lib().rt_partition_pixels(width, height, rank, world, tile, None, C.byref(n))
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error(None).decode())
+    idx = np.zeros(n.value, np.int32)
+    rc = lib().rt_partition_pixels(width, height, rank, world, tile, _ip(idx), C.byref(n))
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error(None).decode())
+    return idx
 
 
 def obj_load(path):

@@ -112,15 +112,14 @@ int alloc_queue(rt_context *c, std::vector<void *> &owner, RayQueue &q, size_t n
 // Pixel-tile partition: tiles row-major over the image,
 // tile_id % world == rank; inside a tile, 8x8 pixel blocks so that one wave
 // (64 consecutive local indices) covers a compact square of the image.
-void build_pixmap(rt_context *c)
+void partition_pixels(int W, int H, int rank, int world, int T, std::vector<uint32_t> &out)
 {
-    const int W = c->width, H = c->height, T = c->tile;
     const int ntx = (W + T - 1) / T, nty = (H + T - 1) / T;
-    c->h_pixmap.clear();
+    out.clear();
     for (int ty = 0; ty < nty; ty++)
         for (int tx = 0; tx < ntx; tx++) {
             int tile_id = ty * ntx + tx;
-            if (tile_id % c->world != c->rank)
+            if (tile_id % world != rank)
                 continue;
             for (int by = 0; by < T; by += 8)
                 for (int bx = 0; bx < T; bx += 8)
@@ -128,9 +127,14 @@ void build_pixmap(rt_context *c)
                         for (int ix = 0; ix < 8; ix++) {
                             int x = tx * T + bx + ix, y = ty * T + by + iy;
                             if (bx + ix < T && by + iy < T && x < W && y < H)
-                                c->h_pixmap.push_back((uint32_t)(y * W + x));
+                                out.push_back((uint32_t)(y * W + x));
                         }
         }
+}
+
+void build_pixmap(rt_context *c)
+{
+    partition_pixels(c->width, c->height, c->rank, c->world, c->tile, c->h_pixmap);
     c->n_local = (uint32_t)c->h_pixmap.size();
 }
 
@@ -367,6 +371,20 @@ extern "C" int rt_set_partition(rt_context *c, int rank, int world, int tile)
     int rc = setup_partition(c);
     if (rc != RT_OK) return rc;
     return do_reset(c);
+}
+
+extern "C" int rt_partition_pixels(int width, int height, int rank, int world, int tile,
+                                   int32_t *indices, int64_t *count)
+{
+    if (width <= 0 || height <= 0 || world < 1 || rank < 0 || rank >= world || tile < 8 ||
+        (tile % 8) != 0 || !count)
+        return fail(nullptr, RT_ERR_INVALID, "rt_partition_pixels: bad argument");
+    std::vector<uint32_t> px;
+    partition_pixels(width, height, rank, world, tile, px);
+    *count = (int64_t)px.size();
+    if (indices)
+        std::memcpy(indices, px.data(), px.size() * sizeof(uint32_t));
+    return RT_OK;
 }
 
 extern "C" int rt_reset(rt_context *c)

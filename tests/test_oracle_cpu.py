@@ -1,0 +1,127 @@
+"""CPU tests of the oracle (no GPU): Philox known answers, the one known answer that comes
+from the reference's own code, the fixed sinf/cosf, and the committed
+golden fixtures."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+from raytracer_amd.scene import CameraArgs, SceneBuilder, translation
+
+from . import orc
+from .golden.make_golden import CASES, load_case
+
+
+def test_philox_random123_known_answers():
+    """Random123 kat_vectors for philox4x32-10 (the generator behind curandStatePhilox4_32_10_t)."""
+    assert orc.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox([0xffffffff] * 4, [0xffffffff] * 2) == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                      [0xa4093822, 0x299f31d0]) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniform_mapping_and_stream_layout():
+    """curand_uniform4: x * 2^-32 + 2^-33 in (0, 1]; key = idx + 332, subsequence = idx."""
+    z = np.load(__file__.replace("test_oracle_cpu.py", "golden/philox_uniform4.npz"))
+    for pi, p in enumerate(z["pixels"]):
+        for d in range(16):
+            u = orc.pixel_uniform4(int(p), d)
+            assert np.array_equal(u, z["u"][pi, d])
+            raw = orc.philox([d, 0, int(p), 0], [int(p) + 332, 0])
+            exp = (np.array(raw, np.uint32).astype(np.float32) * np.float32(2.3283064e-10)
+                   + np.float32(2.3283064e-10) / np.float32(2.0))
+            assert np.array_equal(u, exp.astype(np.float32))
+            assert (u > 0).all() and (u <= 1).all()
+
+
+def test_survey_known_answer():
+    """The only output of the REFERENCE ITSELF available: SURVEY.md section 8(c) recorded, from
+    the reference's per-pixel code built as host C++, sphere + point light at 64x48, centre
+    pixel: t = 5.005611, radiance (0.244406, 0.010100, 0.011608).  The sphere/light/camera are
+    kernel.cu:285-291,301,228-229; the ray is the pixel centre (offset 0.5, 0.5); the
+    Lambertian colour that reproduces the recorded channel ratios is (0.7, 0.2, 0.1)."""
+    b = SceneBuilder()
+    b.add_sphere(0.33, translation(0, 0, -8), color=(0.7, 0.2, 0.1))
+    b.add_point_light((-8, 0, 0), (233.7, 33.8, 77.7))
+    s = b.build()
+    cam = CameraArgs.for_image(64, 48)
+    o, d = orc.camera_ray(cam, [[0.5, 0.5]])
+    for depth in (0, 12):
+        rgb, t, prim = orc.trace_ray(s, o[0], d[0], depth, pixel_index=24 * 64 + 32)
+        assert prim == 0
+        assert abs(float(t) - 5.005611) < 5e-7
+        assert np.allclose(rgb, [0.244406, 0.010100, 0.011608], rtol=0, atol=5e-7)
+
+
+def _ulp_diff(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7fffffff), ai)
+    bi = np.where(bi < 0, -(bi & 0x7fffffff), bi)
+    return np.abs(ai - bi)
+
+
+def test_fixed_sincos_within_1ulp_of_libm():
+    """material.cu:46 calls the platform's sinf/cosf; the build fixes them (double Taylor,
+    rounded).  They must stay within 1 ulp of a correctly rounded result on sampleHemi's range."""
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-np.pi / 4, 3 * np.pi / 4, 20000),
+                        [-np.pi / 4, 0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, 1e-8, -1e-8]])
+    x = x.astype(np.float32)
+    s = np.array([orc.lib().orc_sinf(float(v)) for v in x], np.float32)
+    c = np.array([orc.lib().orc_cosf(float(v)) for v in x], np.float32)
+    rs = np.sin(x.astype(np.float64)).astype(np.float32)
+    rc = np.cos(x.astype(np.float64)).astype(np.float32)
+    big = np.abs(rc) > 1e-6          # relative ulp is meaningless next to cos's zero crossing
+    assert _ulp_diff(s, rs).max() <= 1
+    assert _ulp_diff(c[big], rc[big]).max() <= 1
+    assert np.abs(c[~big] - rc[~big]).max() < 1e-12 if (~big).any() else True
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_golden(name):
+    """The oracle, rebuilt on this machine, reproduces the committed fixtures bit for bit."""
+    scene, cam, w, h, crop, z, meta = load_case(name)
+    for spp, depth in meta["runs"]:
+        r = orc.render(scene, cam, w, h, spp=spp, max_depth=depth, crop=crop)
+        k = f"s{spp}_d{depth}"
+        assert np.array_equal(r["prim_id"], z[k + "_prim"])
+        assert np.array_equal(r["t"].view(np.uint32), z[k + "_t"].view(np.uint32))
+        assert np.array_equal(r["rgba"].view(np.uint32), z[k + "_rgba"].view(np.uint32))
+        assert [r["primary"], r["shadow"], r["bounce"]] == list(z[k + "_rays"])
+
+
+def test_oracle_crop_and_threads_invariant():
+    """A crop equals the same window of the full render; thread count does not matter."""
+    cfg = scenes.c2(64, 36)
+    full = orc.render(cfg.scene, cfg.camera, 64, 36, spp=2, max_depth=3, threads=1)
+    crop = orc.render(cfg.scene, cfg.camera, 64, 36, spp=2, max_depth=3, crop=(8, 4, 40, 30))
+    assert np.array_equal(full["rgba"][4:30, 8:40], crop["rgba"])
+    assert np.array_equal(full["prim_id"][4:30, 8:40], crop["prim_id"])
+
+
+def test_oracle_exact_tie_keeps_first():
+    """H8: two coincident triangles -- strict `t < rec.t` keeps the first in traversal order."""
+    tri = [(-5, -5, -20), (5, -5, -20), (0, 6, -20)]
+    b = SceneBuilder()
+    b.add_triangle(tri, [(0, 0, 1)] * 3)
+    b.add_triangle(tri, [(0, 0, 1)] * 3)
+    s = b.build()
+    t, pid, hit = orc.scene_hit(s, [[0, 0, 0]], [[0, 0, -1]])
+    assert hit[0] == 1 and pid[0] == 0 and t[0] == np.float32(20.0)
+
+
+def test_oracle_postprocess_reference_values():
+    """ACES curve (PostProcess.cuh:29-37) against a float64 evaluation; median of a 3x3 ramp."""
+    x = np.linspace(0, 4, 64, dtype=np.float32)
+    img = np.stack([x, x * 0.5, x * 0.25, np.ones_like(x)], -1).reshape(8, 8, 4)
+    out = orc.tonemap(img)
+    xd = img[..., :3].astype(np.float64)
+    ref = np.clip((xd * (2.51 * xd + 0.03)) / (xd * (2.43 * xd + 0.59) + 0.14), 0, 1)
+    assert np.allclose(out[..., :3], ref, atol=2e-7)
+    assert (out[..., 3] == 1).all()
+    med = orc.median3x3(img)
+    # interior pixel: 9 samples sorted by luma descending, element 4 = the middle one
+    lum = (0.299 * img[..., 0] + 0.587 * img[..., 1] + 0.114 * img[..., 2])
+    w = sorted(lum[2:5, 3:6].reshape(-1), reverse=True)[4]
+    assert np.isclose(0.299 * med[3, 4, 0] + 0.587 * med[3, 4, 1] + 0.114 * med[3, 4, 2], w)

@@ -8,6 +8,7 @@ from raytracer_amd import abi, scenes
 from raytracer_amd.scene import CameraArgs, SceneBuilder, identity, translation
 
 from . import orc
+from .golden.make_golden import CASES, load_case
 
 pytestmark = pytest.mark.gpu
 
@@ -44,6 +45,24 @@ def check_images(got, ref, st=None):
         assert st.primary_rays == ref["primary"]
         assert st.shadow_rays == ref["shadow"]
         assert st.bounce_rays == ref["bounce"]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_fixtures(gpu_ctx_factory, name):
+    """HIP path against the committed fixtures (tests/golden, scene arrays stored inside)."""
+    scene, cam, w, h, crop, z, meta = load_case(name)
+    x0, y0, x1, y1 = crop
+    ctx = gpu_ctx_factory(w, h)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    for spp, depth in meta["runs"]:
+        ctx.reset()
+        ctx.render(spp, depth)
+        got = ctx.read_framebuffer()
+        k = f"s{spp}_d{depth}"
+        assert np.array_equal(got["prim_id"][y0:y1, x0:x1], z[k + "_prim"])
+        assert np.array_equal(got["t"][y0:y1, x0:x1].view(np.uint32), z[k + "_t"].view(np.uint32))
+        assert_radiance(got["rgba"][y0:y1, x0:x1], z[k + "_rgba"])
 
 
 def test_scene_hit_mixed(gpu_ctx_factory):

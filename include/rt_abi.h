@@ -150,6 +150,20 @@ int rt_scene_hit(rt_context *ctx, int n, const float *org, const float *dir, flo
  * [H][W][4]; either may be NULL. */
 int rt_postprocess(rt_context *ctx, float *hdr_rgba, float *filtered_rgba);
 
+/* No counterpart in the reference, whose Scene::hit is a plain scan ("Brute force
+ * method", Scene/Scene.cu:7).  enabled = 1 (default): the closest-hit kernel skips
+ * groups of triangles whose conservative bounding sphere no ray of the wave can hit;
+ * the result is the scan's, bit for bit.  enabled = 0: every ray is tested
+ * against every triangle -- the validation mode the parity tests compare against. */
+int rt_set_culling(rt_context *ctx, int enabled);
+
+/* Host-only view of what rt_upload_scene derives for the culling (no device needed; for
+ * tests and tools): per triangle, in the reference's traversal order, its conservative
+ * bounding sphere bounds[n_tris][4] = (cx, cy, cz, rho) and its position in the device
+ * order; geom_extent = max |coordinate| of the geometry.  Any pointer may be NULL. */
+int rt_host_bounds(const rt_scene_desc *scene, float *bounds, int32_t *position,
+                   float *geom_extent);
+
 int rt_get_stats(rt_context *ctx, rt_stats *stats);
 int rt_reset_stats(rt_context *ctx);
 /* 1: time every closest-hit launch with HIP events (adds a sync per sample). */

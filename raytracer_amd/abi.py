@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_set_partition", "rt_partition_pixels", "rt_reset",
     "rt_render", "rt_read_framebuffer", "rt_local_pixel_count", "rt_local_pixel_indices",
     "rt_export_local_rgba", "rt_scene_hit", "rt_postprocess", "rt_get_stats", "rt_reset_stats",
-    "rt_set_timing", "rt_last_error", "rt_obj_load", "rt_obj_free", "rt_write_ppm", "rt_write_pfm",
+    "rt_set_timing", "rt_set_culling", "rt_host_bounds", "rt_last_error", "rt_obj_load", "rt_obj_free", "rt_write_ppm", "rt_write_pfm",
 ]
 
 
@@ -69,6 +69,8 @@ def lib():
         L.rt_get_stats.argtypes = [VP, C.POINTER(Stats)]
         L.rt_reset_stats.argtypes = [VP]
         L.rt_set_timing.argtypes = [VP, C.c_int]
+        L.rt_set_culling.argtypes = [VP, C.c_int]
+        L.rt_host_bounds.argtypes = [C.POINTER(SceneDesc), FP, IP, FP]
         L.rt_last_error.argtypes = [VP]
         L.rt_last_error.restype = C.c_char_p
         L.rt_obj_load.argtypes = [C.c_char_p, C.POINTER(FP), C.POINTER(FP), C.POINTER(FP),
@@ -189,6 +191,9 @@ class Context:
     def reset_stats(self):
         self._chk(lib().rt_reset_stats(self._h))
 
+    def set_culling(self, enabled=True):
+        self._chk(lib().rt_set_culling(self._h, 1 if enabled else 0))
+
     def set_timing(self, enabled=True):
         self._chk(lib().rt_set_timing(self._h, 1 if enabled else 0))
 
@@ -204,6 +209,18 @@ def partition_pixels(width, height, rank, world, tile=64):
     if rc != RT_OK:
         raise RtError(rc, lib().rt_last_error(None).decode())
     return idx
+
+
+def host_bounds(scene: SceneData):
+    """(bounds[n,4], position[n], geom_extent) of rt_host_bounds: host-only."""
+    d = scene.desc()
+    b = np.zeros((scene.n_tris, 4), np.float32)
+    pos = np.zeros(scene.n_tris, np.int32)
+    ext = C.c_float()
+    rc = lib().rt_host_bounds(C.byref(d), _fp(b), _ip(pos), C.byref(ext))
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error(None).decode())
+    return b, pos, float(ext.value)
 
 
 def obj_load(path):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -41,6 +42,7 @@ struct rt_context {
     bool have_scene = false, have_cam = false;
     int n_lights = 0;
     uint64_t n_prims = 0;
+    float geom_extent = 1.0f;            // max |coordinate| of the uploaded geometry
     int max_blocks = 2048;
 
     DevView v{};
@@ -246,6 +248,21 @@ void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, ui
     c->launches++;
 }
 
+// Culling extent: ray origins inside [-extent, extent]^3 (camera and every hit point)
+// are culled with `slack` covering the fp32 error of p = o + t d and of the sphere
+// tests at that coordinate magnitude; other rays are scanned unculled.
+void update_extent(rt_context *c)
+{
+    float e = std::max(c->geom_extent, 1.0f);
+    if (c->have_cam) {
+        const v3 &p = c->v.cam.pos;
+        float m = std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z)));
+        if (std::isfinite(m)) e = std::max(e, m);
+    }
+    c->v.tree.extent = 4.0f * e;
+    c->v.tree.slack = c->v.tree.extent * (1.0f / 131072.0f);      // 2 * 2^-18 * extent
+}
+
 } // namespace
 
 // =====================================================================================
@@ -271,6 +288,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     c->height = height;
     c->v.width = width;
     c->v.height = height;
+    c->v.cull = 1;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_r0);
@@ -326,8 +344,11 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     DevView &v = c->v;
     TriRec *tris = nullptr; TriCold *cold = nullptr; ModelRec *models = nullptr;
     SphereRec *spheres = nullptr; LightRec *lights = nullptr;
+    NodeRec *nodes = nullptr; uint32_t *pos_of = nullptr;
     if ((rc = dalloc(c, c->scene_allocs, tris, hs.tris.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, cold, hs.cold.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, pos_of, hs.pos_of.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, nodes, hs.nodes.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, models, hs.models.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, spheres, hs.spheres.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, lights, hs.lights.size()))) return rc;
@@ -336,13 +357,22 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     };
     RT_HIP(c, up(tris, hs.tris.data(), hs.tris.size() * sizeof(TriRec)));
     RT_HIP(c, up(cold, hs.cold.data(), hs.cold.size() * sizeof(TriCold)));
+    RT_HIP(c, up(pos_of, hs.pos_of.data(), hs.pos_of.size() * sizeof(uint32_t)));
+    RT_HIP(c, up(nodes, hs.nodes.data(), hs.nodes.size() * sizeof(NodeRec)));
     RT_HIP(c, up(models, hs.models.data(), hs.models.size() * sizeof(ModelRec)));
     RT_HIP(c, up(spheres, hs.spheres.data(), hs.spheres.size() * sizeof(SphereRec)));
     RT_HIP(c, up(lights, hs.lights.data(), hs.lights.size() * sizeof(LightRec)));
-    v.tris = tris; v.tri_cold = cold; v.models = models; v.spheres = spheres; v.lights = lights;
-    v.n_tris = (int)hs.tris.size();
+    v.tris = tris; v.tri_pos_of = pos_of; v.tri_cold = cold; v.models = models;
+    v.spheres = spheres; v.lights = lights;
+    v.n_tris = (int)hs.cold.size();
     v.n_spheres = (int)hs.spheres.size();
     v.n_lights = (int)hs.lights.size();
+    for (int l = 0; l < kMaxLevels; l++)
+        v.tree.level[l] = nodes + hs.level_off[std::min<size_t>((size_t)l, hs.level_off.size() - 1)];
+    v.tree.top = hs.top;
+    v.tree.n_groups0 = (int)(hs.level_cnt[0] / kTreeArity);
+    c->geom_extent = hs.geom_extent;
+    update_extent(c);
     c->n_lights = v.n_lights;
     c->n_prims = (uint64_t)hs.tris.size() + hs.spheres.size();
     if ((rc = alloc_shadow(c))) return rc;
@@ -357,6 +387,7 @@ extern "C" int rt_set_camera(rt_context *c, const rt_camera_desc *cam)
     if (cam->res_x <= 0 || cam->res_y <= 0) return fail(c, RT_ERR_INVALID, "camera resolution must be positive");
     c->v.cam = make_camera(cam);
     c->have_cam = true;
+    update_extent(c);
     return RT_OK;
 }
 
@@ -607,6 +638,33 @@ extern "C" int rt_reset_stats(rt_context *c)
     RT_HIP(c, hipMemset(c->v.ctl, 0, sizeof(Ctl)));
     c->samples = c->primary = c->launches = c->timed_launches = 0;
     c->intersect_ms = c->render_ms = 0.0;
+    return RT_OK;
+}
+
+extern "C" int rt_host_bounds(const rt_scene_desc *d, float *bounds, int32_t *position,
+                              float *geom_extent)
+{
+    HostScene hs;
+    std::string err;
+    int rc = build_host_scene(d, hs, err);
+    if (rc != RT_OK) return fail(nullptr, rc, err);
+    const size_t n = hs.cold.size();
+    for (size_t g = 0; g < n; g++) {
+        const NodeRec &r = hs.nodes[hs.level_off[0] + hs.pos_of[g]];
+        if (bounds) {
+            bounds[4 * g + 0] = r.cx; bounds[4 * g + 1] = r.cy;
+            bounds[4 * g + 2] = r.cz; bounds[4 * g + 3] = r.rho;
+        }
+        if (position) position[g] = (int32_t)hs.pos_of[g];
+    }
+    if (geom_extent) *geom_extent = hs.geom_extent;
+    return RT_OK;
+}
+
+extern "C" int rt_set_culling(rt_context *c, int enabled)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    c->v.cull = enabled != 0;
     return RT_OK;
 }
 

@@ -129,6 +129,102 @@ __device__ __forceinline__ bool tri_hit(const TriRec &T, const v3 &o, const v3 &
     return true;
 }
 
+// ------------------------------------------------------------------ packed pairs
+// Two rays per lane share every wave-uniform operand; ext_vector float2 arithmetic
+// compiles to v_pk_{mul,add}_f32 (IEEE, no contraction), i.e. the same bits as the
+// scalar code above at half the issue slots.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct RayPair {
+    f2 ox, oy, oz, dx, dy, dz;
+    f2 best;          // running closest t per ray (IntersectRecord::t)
+    f2 bestp;         // best * (1 + 2^-19): conservative side of every pre-test
+    int idx, idy;     // reference traversal index of the closest primitive, -1 = none
+    bool wildx, wildy;   // origin outside the culling extent (or not finite): never culled
+};
+
+constexpr float kBestInfl = 1.000002f;
+constexpr float kEpsDefl = kEps * 0.999999f;
+
+// Conservative test of one bounding sphere (centre c, radius rho, rho2 >= rho^2)
+// against both rays: true = some triangle below the node may still be accepted.
+//   line:   |(c - o) x d|^2 > rho^2              -> the ray's line misses the sphere
+//   depth:  (c - o).d - rho > best (inflated)    -> the sphere starts beyond the closest hit
+//   behind: (c - o).d + rho < 0                  -> the sphere lies behind the origin
+__device__ __forceinline__ void node_test(const RayPair &r, float cx, float cy, float cz, float rho,
+                                          float rho2, bool &px, bool &py)
+{
+    f2 mx = cx - r.ox, my = cy - r.oy, mz = cz - r.oz;
+    f2 kx = my * r.dz - mz * r.dy, ky = mz * r.dx - mx * r.dz, kz = mx * r.dy - my * r.dx;
+    f2 q = kx * kx + ky * ky + kz * kz;
+    f2 md = mx * r.dx + my * r.dy + mz * r.dz;
+    f2 near = md - rho, far = md + rho;
+    bool rx = (q.x > rho2) | (near.x > r.bestp.x) | (far.x < 0.0f);
+    bool ry = (q.y > rho2) | (near.y > r.bestp.y) | (far.y < 0.0f);
+    px = !rx | r.wildx;
+    py = !ry | r.wildy;
+}
+
+// Triangle::hit (Model/Model.cu:91-137) for both rays of a pair against one
+// (wave-uniform) triangle.  The acceptance conditions are a pure conjunction; two of
+// them get a cheap conservative pre-test so that the IEEE divide and the three IEEE
+// square roots run only for rays that can still pass:
+//   window  t in (eps, best): tested as (num - eps' dnd)(best' dnd - num) >= 0 first
+//   area    s1 + s2 + s3 - S <= 0.001: impossible once one |cross|^2 exceeds T.qmax
+// Exact ties in t go to the lower reference index (H8: the reference, scanning in
+// index order with strict <, keeps the first).
+__device__ __forceinline__ void tri_test_pair(const TriRec &T, RayPair &r, bool cx, bool cy)
+{
+    f2 dnd = T.nx * r.dx + T.ny * r.dy + T.nz * r.dz;                         // :98
+    cx = cx & !(fabsf(dnd.x) < kEps);                                          // :99
+    cy = cy & !(fabsf(dnd.y) < kEps);
+    f2 num = -(r.ox * T.nx + r.oy * T.ny + r.oz * T.nz) + T.dn;               // :102 numerator
+    f2 u = num - kEpsDefl * dnd, w = r.bestp * dnd - num;
+    f2 uw = u * w;
+    cx = cx & !(uw.x < 0.0f);
+    cy = cy & !(uw.y < 0.0f);
+    if (!(cx | cy))
+        return;
+    f2 t;
+    t.x = num.x / dnd.x;                                                       // :102
+    t.y = num.y / dnd.y;
+    cx = cx & (t.x > kEps) & ((t.x < r.best.x) | ((t.x == r.best.x) & (T.orig < r.idx)));   // :120
+    cy = cy & (t.y > kEps) & ((t.y < r.best.y) | ((t.y == r.best.y) & (T.orig < r.idy)));
+    if (!(cx | cy))
+        return;
+    f2 px = r.ox + t * r.dx, py = r.oy + t * r.dy, pz = r.oz + t * r.dz;       // :104
+    f2 ax = px - T.ax, ay = py - T.ay, az = pz - T.az;
+    f2 bx = px - T.bx, by = py - T.by, bz = pz - T.bz;
+    f2 ex = px - T.cx, ey = py - T.cy, ez = pz - T.cz;
+    // cross(p - a, p - b), cross(p - c, p - a), cross(p - c, p - b)             :107-109
+    f2 c1x = ay * bz - az * by, c1y = az * bx - ax * bz, c1z = ax * by - ay * bx;
+    f2 c2x = ey * az - ez * ay, c2y = ez * ax - ex * az, c2z = ex * ay - ey * ax;
+    f2 c3x = ey * bz - ez * by, c3y = ez * bx - ex * bz, c3z = ex * by - ey * bx;
+    f2 q1 = c1x * c1x + c1y * c1y + c1z * c1z;
+    f2 q2 = c2x * c2x + c2y * c2y + c2z * c2z;
+    f2 q3 = c3x * c3x + c3y * c3y + c3z * c3z;
+    cx = cx & !((q1.x > T.qmax) | (q2.x > T.qmax) | (q3.x > T.qmax));
+    cy = cy & !((q1.y > T.qmax) | (q2.y > T.qmax) | (q3.y > T.qmax));
+    if (!(cx | cy))
+        return;
+    if (cx) {
+        float s1 = sqrtf(q1.x), s2 = sqrtf(q2.x), s3 = sqrtf(q3.x);
+        if (!(fabsf(s1 + s2 + s3 - T.S) > 0.001f)) {                           // :113
+            r.best.x = t.x;
+            r.bestp.x = t.x * kBestInfl;
+            r.idx = T.orig;
+        }
+    }
+    if (cy) {
+        float s1 = sqrtf(q1.y), s2 = sqrtf(q2.y), s3 = sqrtf(q3.y);
+        if (!(fabsf(s1 + s2 + s3 - T.S) > 0.001f)) {
+            r.best.y = t.y;
+            r.bestp.y = t.y * kBestInfl;
+            r.idy = T.orig;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ sphere
 // Quadratic::hit (Model/Model.cu:349-410) up to the acceptance test :396.
 __device__ __forceinline__ bool sphere_hit(const SphereRec &S, const v3 &o, const v3 &d, float best,

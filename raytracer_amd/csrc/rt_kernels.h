@@ -24,13 +24,27 @@ struct RayQueue {
     uint32_t *path;        // local path (pixel) index; unused for shadow queues
 };
 
+// Implicit 4-ary bounding-sphere tree over the triangle records (rt_math.h NodeRec;
+// built by rt_upload.cpp).  Children of node i of level l+1 are nodes 4i..4i+3 of
+// level l, so a child group is one aligned 64-byte block: no pointers, no stack.
+struct TreeView {
+    const NodeRec *level[kMaxLevels];
+    int top;               // the top level holds one group of at most 4 nodes
+    int n_groups0;         // number of 4-triangle groups of level 0
+    float extent;          // rays whose origin leaves [-extent, extent]^3 are never culled
+    float slack;           // added to every rho: fp32 error of the ray-side arithmetic
+};
+
 struct DevView {
     int width, height;
     int cnt;                        // 1-based sample index (*cnt of kernel.cu:52-66)
     CameraRec cam;
     // scene (read-only)
-    const TriRec *tris;
-    const TriCold *tri_cold;
+    const TriRec *tris;             // tree order
+    const uint32_t *tri_pos_of;     // reference traversal index -> position in tris
+    const TriCold *tri_cold;        // reference traversal order
+    TreeView tree;
+    int cull;                       // 0: scan every triangle (validation), 1: use the tree
     const ModelRec *models;
     const SphereRec *spheres;
     const LightRec *lights;

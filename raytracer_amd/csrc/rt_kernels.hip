@@ -68,50 +68,160 @@ __global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t
 }
 
 // ------------------------------------------------------------------ closest hit
-// Scene::hit (Scene.cu:8-67): every ray against every primitive in the reference's
-// order -- triangles (standalone models, then each mesh's table), then quadrics.
-// A wave owns 64 rays; the triangle record is wave-uniform, so it is fetched
-// through the scalar data path (s_load) and consumed as SGPR operands.  Strict
-// `t < best` in ascending index order keeps the first primitive on exact ties (H8).
-__global__ __launch_bounds__(kBlock) void k_intersect(const TriRec *__restrict__ tris, int n_tris,
+// Scene::hit (Scene.cu:8-67): the closest of all primitives the reference's scan would
+// accept -- min over (t, reference index) -- found without visiting most of them.
+//
+// A wave owns 64 * 2P rays (P packed pairs per lane).  The triangle side is
+// wave-uniform: node and triangle records come through the scalar data path, one
+// aligned 64-byte block (s_load_dwordx16) per group of four nodes / per triangle, and
+// sit in SGPRs as operands of packed fp32 VALU ops.  Traversal of the implicit 4-ary
+// sphere tree is stackless: the state is (level, group index, 4 pending-child bits per
+// level packed in one 64-bit scalar), all in SGPRs; a group is expanded when any ray
+// of the wave may still hit below it.  The tests of node_test() only ever discard
+// (ray, triangle) pairs Triangle::hit would reject, so the result is the scan's.
+// CULL = false visits every triangle (validation mode, rt_set_culling(ctx, 0)).
+template <int P>
+struct WaveRays {
+    RayPair r[P];
+};
+
+template <int P>
+__device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, uint32_t node,
+                                              WaveRays<P> &w, uint32_t lanebits, int j)
+{
+    const TriRec T = tris[node];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        bool cx = (lanebits >> (j * 2 * P + 2 * p)) & 1u, cy = (lanebits >> (j * 2 * P + 2 * p + 1)) & 1u;
+        if (__ballot(cx | cy))
+            tri_test_pair(T, w.r[p], cx, cy);
+    }
+}
+
+template <int P, bool CULL>
+__global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec *__restrict__ tris,
                                                       const SphereRec *__restrict__ spheres,
-                                                      int n_spheres, RayQueue q,
+                                                      int n_tris, int n_spheres, RayQueue q,
                                                       const uint32_t *__restrict__ count_ptr,
                                                       float *__restrict__ out_t,
                                                       int32_t *__restrict__ out_id)
 {
+    constexpr uint32_t R = 2 * P;
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
-    for (uint32_t base = wave * 64u; base < count; base += n_waves * 64u) {
-        uint32_t i = base + lane;
-        bool valid = i < count;
-        v3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(0.0f, 0.0f, 0.0f);
-        if (valid) {
-            o = mk3(q.ox[i], q.oy[i], q.oz[i]);
-            d = mk3(q.dx[i], q.dy[i], q.dz[i]);
-        }
-        float best = kInf;                  // IntersectRecord(): t = INF
-        int32_t id = -1;
-        for (int g = 0; g < n_tris; g++) {
-            const TriRec T = tris[g];
-            float t;
-            if (tri_hit(T, o, d, best, t)) {
-                best = t;
-                id = g;
+    for (uint32_t base = wave * 64u * R; base < count; base += n_waves * 64u * R) {
+        WaveRays<P> w;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            RayPair &r = w.r[p];
+            uint32_t i0 = base + (2 * p) * 64u + lane, i1 = i0 + 64u;
+            // rays past the end of the queue: parked far away with an empty t window
+            float o0[3] = {0.0f, 1e18f, 0.0f}, d0[3] = {1.0f, 0.0f, 0.0f};
+            float o1[3] = {0.0f, 1e18f, 0.0f}, d1[3] = {1.0f, 0.0f, 0.0f};
+            float b0 = 0.0f, b1 = 0.0f;
+            if (i0 < count) {
+                o0[0] = q.ox[i0]; o0[1] = q.oy[i0]; o0[2] = q.oz[i0];
+                d0[0] = q.dx[i0]; d0[1] = q.dy[i0]; d0[2] = q.dz[i0];
+                b0 = kInf;                                   // IntersectRecord(): t = INF
             }
-        }
-        for (int s = 0; s < n_spheres; s++) {
-            float t;
-            if (sphere_hit(spheres[s], o, d, best, t)) {
-                best = t;
-                id = n_tris + s;
+            if (i1 < count) {
+                o1[0] = q.ox[i1]; o1[1] = q.oy[i1]; o1[2] = q.oz[i1];
+                d1[0] = q.dx[i1]; d1[1] = q.dy[i1]; d1[2] = q.dz[i1];
+                b1 = kInf;
             }
+            r.ox = f2{o0[0], o1[0]}; r.oy = f2{o0[1], o1[1]}; r.oz = f2{o0[2], o1[2]};
+            r.dx = f2{d0[0], d1[0]}; r.dy = f2{d0[1], d1[1]}; r.dz = f2{d0[2], d1[2]};
+            r.best = f2{b0, b1};
+            r.bestp = r.best * kBestInfl;
+            r.idx = -1; r.idy = -1;
+            const float E = tv.extent;
+            r.wildx = (i0 < count) & !((fabsf(o0[0]) <= E) & (fabsf(o0[1]) <= E) & (fabsf(o0[2]) <= E) &
+                                      (fabsf(d0[0]) <= 2.0f) & (fabsf(d0[1]) <= 2.0f) & (fabsf(d0[2]) <= 2.0f));
+            r.wildy = (i1 < count) & !((fabsf(o1[0]) <= E) & (fabsf(o1[1]) <= E) & (fabsf(o1[2]) <= E) &
+                                      (fabsf(d1[0]) <= 2.0f) & (fabsf(d1[1]) <= 2.0f) & (fabsf(d1[2]) <= 2.0f));
         }
-        if (valid) {
-            out_t[i] = best;
-            out_id[i] = id;
+
+        if (CULL) {
+            int l = tv.top;
+            uint32_t g = 0;
+            unsigned long long pending = 0;      // 4 child bits per level
+            uint32_t lanebits = 0;               // level 0: which (triangle, ray) pairs passed
+            bool expand = true;
+            for (;;) {
+                if (expand) {
+                    const NodeRec *grp = tv.level[l] + (size_t)g * kTreeArity;
+                    const NodeRec n0 = grp[0], n1 = grp[1], n2 = grp[2], n3 = grp[3];
+                    const NodeRec nn[4] = {n0, n1, n2, n3};
+                    uint32_t m = 0, lb = 0;
+#pragma unroll
+                    for (int j = 0; j < kTreeArity; j++) {
+                        float rho = nn[j].rho + tv.slack, rho2 = rho * rho;
+                        bool any = false;
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            bool px, py;
+                            node_test(w.r[p], nn[j].cx, nn[j].cy, nn[j].cz, rho, rho2, px, py);
+                            any |= px | py;
+                            lb |= ((uint32_t)px << (j * 2 * P + 2 * p)) | ((uint32_t)py << (j * 2 * P + 2 * p + 1));
+                        }
+                        // rho = -inf (padding, or a triangle Model.cu:99 always rejects) is
+                        // dead for every ray, including the unculled ones
+                        if (__ballot(any) && nn[j].rho > -__builtin_huge_valf())
+                            m |= 1u << j;
+                    }
+                    pending |= (unsigned long long)m << (4 * l);
+                    if (l == 0)
+                        lanebits = lb;
+                    expand = false;
+                }
+                uint32_t m = (uint32_t)(pending >> (4 * l)) & 15u;
+                if (m == 0) {
+                    if (l == tv.top)
+                        break;
+                    l++;
+                    g >>= 2;
+                    continue;
+                }
+                int j = __builtin_ctz(m);
+                pending &= ~(1ull << (4 * l + j));
+                uint32_t node = g * kTreeArity + (uint32_t)j;
+                if (l == 0) {
+                    test_triangle<P>(tris, node, w, lanebits, j);
+                } else {
+                    l--;
+                    g = node;
+                    expand = true;
+                }
+            }
+        } else {
+            for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
+                test_triangle<P>(tris, node, w, 0xffffffffu, 0);
+        }
+
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            RayPair &r = w.r[p];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t i = base + (2 * p + h) * 64u + lane;
+                v3 o = mk3(h ? r.ox.y : r.ox.x, h ? r.oy.y : r.oy.x, h ? r.oz.y : r.oz.x);
+                v3 d = mk3(h ? r.dx.y : r.dx.x, h ? r.dy.y : r.dy.x, h ? r.dz.y : r.dz.x);
+                float best = h ? r.best.y : r.best.x;
+                int32_t id = h ? r.idy : r.idx;
+                for (int s = 0; s < n_spheres; s++) {       // quadrics come last (Scene.cu:31-37)
+                    float t;
+                    if (sphere_hit(spheres[s], o, d, best, t)) {
+                        best = t;
+                        id = n_tris + s;
+                    }
+                }
+                if (i < count) {
+                    out_t[i] = best;
+                    out_id[i] = id;
+                }
+            }
         }
     }
 }
@@ -120,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const TriRec *__restrict__
 __device__ __forceinline__ void fill_hit(const DevView &v, const Ray &r, int32_t id, Hit &h)
 {
     if (id < v.n_tris)
-        fill_tri_hit(v.tris[id], v.tri_cold[id], v.models[v.tri_cold[id].model], r, h);
+        fill_tri_hit(v.tris[v.tri_pos_of[id]], v.tri_cold[id], v.models[v.tri_cold[id].model], r, h);
     else
         fill_sphere_hit(v.spheres[id - v.n_tris], r, h);
 }
@@ -506,8 +616,21 @@ void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n)
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
                       uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks)
 {
-    k_intersect<<<grid_for(capacity, max_blocks), kBlock, 0, s>>>(
-        v.tris, v.n_tris, v.spheres, v.n_spheres, q, count, out_t, out_id);
+    // 4 rays per lane when that still leaves every SIMD several waves, else 2
+    const bool wide = capacity >= (1u << 20);
+    const uint32_t rays_per_block = kBlock * (wide ? 4u : 2u);
+    uint32_t g = (capacity + rays_per_block - 1) / rays_per_block;
+    if (g < 1) g = 1;
+    if ((int)g > max_blocks) g = (uint32_t)max_blocks;
+#define RT_LAUNCH_INTERSECT(P, CULL)                                                           \
+    k_intersect<P, CULL><<<g, kBlock, 0, s>>>(v.tree, v.tris, v.spheres, v.n_tris, v.n_spheres, \
+                                              q, count, out_t, out_id)
+    if (v.cull) {
+        if (wide) RT_LAUNCH_INTERSECT(2, true); else RT_LAUNCH_INTERSECT(1, true);
+    } else {
+        if (wide) RT_LAUNCH_INTERSECT(2, false); else RT_LAUNCH_INTERSECT(1, false);
+    }
+#undef RT_LAUNCH_INTERSECT
 }
 
 void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,

@@ -146,20 +146,38 @@ constexpr int kMatLambertian = 1;           // Material/Object.cuh:15
 constexpr int kMatSpecularBit = 4;          // Material/Object.cuh:10
 
 // ---- device-resident scene records (built on the host at upload) ----
-// One 64-byte record per triangle, in the reference's traversal order.  Every
-// field is a ray-independent sub-expression of Triangle::hit (Model/Model.cu:91-137)
-// evaluated with the reference's own operation order:
+// One 64-byte record per triangle.  Every arithmetic field is a ray-independent
+// sub-expression of Triangle::hit (Model/Model.cu:91-137) evaluated with the
+// reference's own operation order:
 //   a,b,c = transformation(pos[i])             (:94, Matrix.cu:85-91)
 //   n     = cross(a - c, b - c)                (:97)
 //   dn    = dot(a, n)                          (:102, second term)
 //   S     = 2.0f * area()                      (:106, :413-420)
+// The records are stored in TRAVERSAL-TREE order (rt_upload.cpp: Morton order of the
+// bounding-sphere centres); `orig` is the triangle's index in the reference's own
+// traversal order (Scene.cu:13-41), which is what the id buffer reports and what
+// breaks exact ties in t (hazard H8: the reference keeps the first one).
+//   qmax  = upper bound on any |cross|^2 of Model.cu:107-109 for which the area test
+//           :113 can still pass: ((S + 0.001) * (1 + 1e-5))^2 rounded up.
 struct TriRec {
     float ax, ay, az, dn;
     float bx, by, bz, S;
-    float cx, cy, cz, pad0;
-    float nx, ny, nz, pad1;
+    float cx, cy, cz;
+    int32_t orig;
+    float nx, ny, nz, qmax;
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+// Conservative bounding sphere of everything Triangle::hit can accept for one triangle
+// (leaf) or for four children (inner node): centre and radius, 16 bytes.  A ray whose
+// line misses the sphere, or whose reach [0.01, best) along the ray misses it, cannot
+// be accepted by any triangle below the node (derivation in DESIGN.md, "Culling is
+// results-identical").  rho = -inf: nothing below can ever be hit; +inf: never culled.
+struct NodeRec { float cx, cy, cz, rho; };
+static_assert(sizeof(NodeRec) == 16, "NodeRec must be 16 bytes");
+
+constexpr int kTreeArity = 4;        // children per node = one 64-byte scalar load
+constexpr int kMaxLevels = 16;       // 4^16 leaves
 
 // Read only for the winning triangle (Model.cu:122-131).
 struct TriCold {

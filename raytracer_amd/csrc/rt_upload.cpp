@@ -6,7 +6,9 @@
 #include "rt_upload.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <thread>
 
 namespace rt {
@@ -37,14 +39,270 @@ static void build_tri(const rt_scene_desc *d, int g, TriRec &T, TriCold &C)
     T.nx = n.x; T.ny = n.y; T.nz = n.z;
     T.dn = dot(ta, n);          // Model.cu:102 second term
     T.S = 2.0f * area;          // Model.cu:106
-    T.pad0 = 0.0f;
-    T.pad1 = 0.0f;
+    T.orig = g;
+    // Largest |cross|^2 (Model.cu:107-109) with which the area test (:113) can pass:
+    // one s_i alone above (S + 0.001)(1 + 1e-5) already puts s1+s2+s3-S beyond 0.001.
+    {
+        double q = ((double)T.S + 0.001) * (1.0 + 1e-5);
+        q *= q;
+        float qf = (float)q;
+        if (!(qf >= q)) qf = std::nextafter(qf, std::numeric_limits<float>::infinity());
+        T.qmax = std::isfinite(q) ? qf : std::numeric_limits<float>::infinity();
+    }
     std::memcpy(C.n0, nn, 3 * sizeof(float));
     std::memcpy(C.n1, nn + 3, 3 * sizeof(float));
     std::memcpy(C.n2, nn + 6, 3 * sizeof(float));
     C.model = model;
     C.pad[0] = C.pad[1] = 0;
 }
+
+// ------------------------------------------------------------------ culling bounds
+// Everything below runs in double on the float values the kernels will see; results
+// are rounded UP to float.  DESIGN.md ("Culling is results-identical") has the proof
+// sketch; the short form:
+//   Triangle::hit accepts a point p only if fl(s1+s2+s3) - S <= 0.001 (Model.cu:113).
+//   In exact arithmetic s1+s2+s3 - S = 2 * sum over edges p lies outside of
+//   (edge length * distance to the edge line) for p in the plane, and grows like
+//   sqrt(S^2 + P^2 h^2) - S with the height h above it.  With x = 0.001 + the fp32
+//   evaluation error, p must therefore lie within
+//       delta = x / k + sqrt(2 S x + x^2) / P,   k = 2 e_min sin(theta_min / 2)
+//   of the triangle, hence within r0 + delta of the centre of its enclosing circle.
+namespace {
+
+struct Bound { double c[3]; double rho; };
+const double kInfD = std::numeric_limits<double>::infinity();
+
+inline double len3(const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+inline double dist3(const double *a, const double *b)
+{
+    double d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+    return len3(d);
+}
+inline void cross3d(const double *a, const double *b, double *r)
+{
+    r[0] = a[1] * b[2] - a[2] * b[1];
+    r[1] = a[2] * b[0] - a[0] * b[2];
+    r[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline float round_up(double v)
+{
+    if (!(v == v)) return std::numeric_limits<float>::infinity();
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+Bound leaf_bound(const TriRec &T)
+{
+    Bound B{{0.0, 0.0, 0.0}, kInfD};
+    const double a[3] = {T.ax, T.ay, T.az}, b[3] = {T.bx, T.by, T.bz}, c[3] = {T.cx, T.cy, T.cz};
+    const double n1 = std::fabs((double)T.nx) + std::fabs((double)T.ny) + std::fabs((double)T.nz);
+    for (int i = 0; i < 3; i++)
+        if (!std::isfinite(a[i]) || !std::isfinite(b[i]) || !std::isfinite(c[i])) return B;
+    if (!std::isfinite(n1) || !std::isfinite((double)T.S)) return B;
+    // |dot(norma, dir)| <= |norma|_1 (1 + ulps) < 0.01: Model.cu:99 rejects every ray (H1)
+    if (n1 * 1.00001 < 0.01) { B.rho = -kInfD; return B; }
+    double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    double v[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    double w[3] = {c[0] - b[0], c[1] - b[1], c[2] - b[2]};
+    double eab = len3(u), eca = len3(v), ebc = len3(w);
+    double emin = std::min(eab, std::min(eca, ebc)), P = eab + eca + ebc;
+    double cr[3];
+    cross3d(u, v, cr);
+    double Sd = len3(cr);
+    if (!(emin > 0.0) || !(Sd > 0.0)) return B;
+    // smallest vertex angle, from the law of cosines
+    auto ang = [](double opp, double s1, double s2) {
+        double cs = (s1 * s1 + s2 * s2 - opp * opp) / (2.0 * s1 * s2);
+        return std::acos(std::max(-1.0, std::min(1.0, cs)));
+    };
+    double th = std::min(ang(ebc, eab, eca), std::min(ang(eca, eab, ebc), ang(eab, eca, ebc)));
+    double k = 2.0 * emin * std::sin(0.5 * th);
+    if (!(k > 0.0)) return B;
+    // centre: midpoint of the longest edge if it covers the third vertex, else circumcentre
+    double ctr[3];
+    {
+        const double *p0 = a, *p1 = b, *p2 = c;
+        double e = eab;
+        if (ebc > e) { p0 = b; p1 = c; p2 = a; e = ebc; }
+        if (eca > e) { p0 = c; p1 = a; p2 = b; e = eca; }
+        for (int i = 0; i < 3; i++) ctr[i] = 0.5 * (p0[i] + p1[i]);
+        if (dist3(ctr, p2) > 0.5 * e) {
+            double vw[3], wu[3], uu = eab * eab, vv = eca * eca, ww = Sd * Sd;
+            cross3d(v, cr, vw);
+            cross3d(cr, u, wu);
+            for (int i = 0; i < 3; i++) ctr[i] = a[i] + (uu * vw[i] + vv * wu[i]) / (2.0 * ww);
+        }
+    }
+    float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
+    double cd[3] = {cf[0], cf[1], cf[2]};
+    if (!std::isfinite(cd[0]) || !std::isfinite(cd[1]) || !std::isfinite(cd[2])) return B;
+    double r0 = std::max(dist3(cd, a), std::max(dist3(cd, b), dist3(cd, c)));
+    // fixed point of delta = f(x(delta)); gamma bounds the fp32 error of one |cross|
+    const double gamma = 1.0 / 1048576.0;
+    auto f = [&](double delta) {
+        double D = 2.0 * r0 + delta;
+        double x = 0.001 * (1.0 + 1e-6) + std::fabs((double)T.S - Sd) + 6.0 * gamma * D * D +
+                   gamma * (Sd + 0.001);
+        return x / k + std::sqrt(2.0 * Sd * x + x * x) / P;
+    };
+    double delta = 0.0;
+    for (int it = 0; it < 16; it++) delta = f(delta);
+    delta = 1.5 * delta + 1e-6 * r0;
+    if (!std::isfinite(delta) || f(delta) > delta) return B;          // no consistent bound
+    B.c[0] = cd[0]; B.c[1] = cd[1]; B.c[2] = cd[2];
+    B.rho = (r0 + delta) * (1.0 + 1e-5);
+    return B;
+}
+
+// smallest sphere around two spheres
+void merge(Bound &A, const Bound &Bq)
+{
+    double d = dist3(A.c, Bq.c);
+    if (d + Bq.rho <= A.rho) return;
+    if (d + A.rho <= Bq.rho) { A = Bq; return; }
+    double R = 0.5 * (d + A.rho + Bq.rho);
+    double s = d > 0.0 ? (R - A.rho) / d : 0.0;
+    for (int i = 0; i < 3; i++) A.c[i] += (Bq.c[i] - A.c[i]) * s;
+    A.rho = R;
+}
+
+NodeRec parent_of(const NodeRec *ch, int n)
+{
+    NodeRec out{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+    Bound acc{{0, 0, 0}, -kInfD};
+    bool have = false;
+    for (int i = 0; i < n; i++) {
+        double r = ch[i].rho;
+        if (r == -kInfD) continue;
+        if (!(r < kInfD)) { out.rho = std::numeric_limits<float>::infinity(); return out; }
+        Bound b{{ch[i].cx, ch[i].cy, ch[i].cz}, r};
+        if (!have) { acc = b; have = true; }
+        else merge(acc, b);
+    }
+    if (!have) return out;
+    out.cx = (float)acc.c[0]; out.cy = (float)acc.c[1]; out.cz = (float)acc.c[2];
+    double cd[3] = {out.cx, out.cy, out.cz}, rho = 0.0;
+    for (int i = 0; i < n; i++) {
+        if (ch[i].rho == -std::numeric_limits<float>::infinity()) continue;
+        double cc[3] = {ch[i].cx, ch[i].cy, ch[i].cz};
+        rho = std::max(rho, dist3(cd, cc) + (double)ch[i].rho);
+    }
+    out.rho = round_up(rho * (1.0 + 1e-6));
+    if (!std::isfinite(cd[0]) || !std::isfinite(cd[1]) || !std::isfinite(cd[2]))
+        out.rho = std::numeric_limits<float>::infinity();
+    return out;
+}
+
+inline uint64_t spread21(uint64_t x)
+{
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+template <class F>
+void parallel_for(size_t n, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+    if (n < 65536) nthreads = 1;
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nthreads; w++)
+        pool.emplace_back([&, w]() {
+            size_t lo = n * w / nthreads, hi = n * (w + 1) / nthreads;
+            for (size_t g = lo; g < hi; g++) fn(g);
+        });
+    for (auto &t : pool) t.join();
+}
+
+// Order the triangles along a Morton curve of their bound centres and stack the
+// implicit 4-ary sphere tree on top.  `tris` arrives in reference traversal order.
+void build_tree(HostScene &hs)
+{
+    const size_t n = hs.tris.size();
+    const float ninf = -std::numeric_limits<float>::infinity();
+    std::vector<Bound> lb(n);
+    parallel_for(n, [&](size_t g) { lb[g] = leaf_bound(hs.tris[g]); });
+
+    double lo[3] = {kInfD, kInfD, kInfD}, hi[3] = {-kInfD, -kInfD, -kInfD}, ext = 0.0;
+    for (size_t g = 0; g < n; g++) {
+        const TriRec &T = hs.tris[g];
+        const float vv[9] = {T.ax, T.ay, T.az, T.bx, T.by, T.bz, T.cx, T.cy, T.cz};
+        for (float x : vv)
+            if (std::isfinite(x)) ext = std::max(ext, (double)std::fabs(x));
+        if (std::isfinite(lb[g].rho))
+            for (int i = 0; i < 3; i++) {
+                lo[i] = std::min(lo[i], lb[g].c[i]);
+                hi[i] = std::max(hi[i], lb[g].c[i]);
+            }
+    }
+    for (const SphereRec &S : hs.spheres) {
+        double r = std::fabs((double)S.rad);
+        for (int i = 0; i < 3; i++) {
+            double row = std::fabs((double)S.M.v[i][0]) + std::fabs((double)S.M.v[i][1]) +
+                         std::fabs((double)S.M.v[i][2]);
+            double e = std::fabs((double)S.M.v[i][3]) + r * row;
+            if (std::isfinite(e)) ext = std::max(ext, e);
+        }
+    }
+    hs.geom_extent = (float)std::min(std::max(ext, 1.0), 1e30);
+
+    std::vector<std::pair<uint64_t, uint32_t>> key(n);
+    parallel_for(n, [&](size_t g) {
+        uint64_t kx = 0;
+        if (std::isfinite(lb[g].rho)) {
+            uint64_t q[3];
+            for (int i = 0; i < 3; i++) {
+                double w = hi[i] - lo[i];
+                double u = w > 0.0 ? (lb[g].c[i] - lo[i]) / w : 0.0;
+                q[i] = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
+            }
+            kx = spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2;
+        }
+        key[g] = {kx, (uint32_t)g};
+    });
+    std::sort(key.begin(), key.end());
+
+    const size_t n_pad = std::max<size_t>(kTreeArity, (n + kTreeArity - 1) / kTreeArity * kTreeArity);
+    std::vector<TriRec> sorted(n_pad);
+    std::memset(sorted.data(), 0, n_pad * sizeof(TriRec));     // padding: norma = 0, never hit
+    hs.pos_of.assign(n, 0u);
+    std::vector<NodeRec> level(n_pad, NodeRec{0.0f, 0.0f, 0.0f, ninf});
+    parallel_for(n, [&](size_t pos) {
+        uint32_t g = key[pos].second;
+        sorted[pos] = hs.tris[g];
+        hs.pos_of[g] = (uint32_t)pos;
+        const Bound &b = lb[g];
+        NodeRec r{(float)b.c[0], (float)b.c[1], (float)b.c[2], 0.0f};
+        r.rho = b.rho == -kInfD ? ninf : round_up(b.rho);
+        level[pos] = r;
+    });
+    for (size_t pos = n; pos < n_pad; pos++) sorted[pos].orig = -1;
+    hs.tris.swap(sorted);
+
+    hs.nodes.clear();
+    hs.level_off.clear();
+    hs.level_cnt.clear();
+    for (;;) {
+        hs.level_off.push_back(hs.nodes.size());
+        hs.level_cnt.push_back((uint32_t)level.size());
+        hs.nodes.insert(hs.nodes.end(), level.begin(), level.end());
+        if (level.size() <= (size_t)kTreeArity) break;
+        size_t np = level.size() / kTreeArity;
+        size_t np_pad = (np + kTreeArity - 1) / kTreeArity * kTreeArity;
+        std::vector<NodeRec> up(np_pad, NodeRec{0.0f, 0.0f, 0.0f, ninf});
+        parallel_for(np, [&](size_t i) { up[i] = parent_of(&level[i * kTreeArity], kTreeArity); });
+        level.swap(up);
+    }
+    hs.top = (int)hs.level_cnt.size() - 1;
+}
+
+} // namespace
 
 int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
 {
@@ -98,19 +356,8 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
 
     out.tris.resize((size_t)d->n_tris);
     out.cold.resize((size_t)d->n_tris);
-    {
-        unsigned hw = std::thread::hardware_concurrency();
-        int nthreads = (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
-        if (d->n_tris < 65536) nthreads = 1;
-        std::vector<std::thread> pool;
-        for (int w = 0; w < nthreads; w++)
-            pool.emplace_back([&, w]() {
-                size_t lo = (size_t)d->n_tris * w / nthreads, hi = (size_t)d->n_tris * (w + 1) / nthreads;
-                for (size_t g = lo; g < hi; g++)
-                    build_tri(d, (int)g, out.tris[g], out.cold[g]);
-            });
-        for (auto &t : pool) t.join();
-    }
+    parallel_for((size_t)d->n_tris,
+                 [&](size_t g) { build_tri(d, (int)g, out.tris[g], out.cold[g]); });
 
     out.models.resize((size_t)n_models);
     for (int m = 0; m < n_models; m++) {
@@ -131,6 +378,9 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
         S.rad2 = S.rad * S.rad;                           // Model.cu:364
         S.model = model;
     }
+
+    build_tree(out);
+    if (out.top >= kMaxLevels) { err = "too many triangles for the traversal tree"; return RT_ERR_UNSUPPORTED; }
 
     out.lights.resize((size_t)d->n_point_lights);
     for (int j = 0; j < d->n_point_lights; j++) {

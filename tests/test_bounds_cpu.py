@@ -1,0 +1,105 @@
+"""Host-side culling bounds (rt_host_bounds, no GPU): whenever the oracle's Triangle::hit
+accepts a (ray, triangle) pair, the conservative sphere test the closest-hit kernel runs
+(rt_device.h node_test, restated here in numpy float32) must let that pair through."""
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+from raytracer_amd.scene import SceneBuilder, identity
+
+from . import orc
+
+
+def node_pass(bound, org, dirn, extent_geom, best=np.float32(1e6)):
+    """node_test of rt_device.h for n rays against one sphere, float32 throughout."""
+    f = np.float32
+    extent = f(4.0) * max(f(extent_geom), f(1.0))
+    slack = extent * f(1.0 / 131072.0)
+    c = bound[:3].astype(f)
+    rho = f(bound[3]) + slack
+    rho2 = rho * rho
+    m = c[None, :] - org
+    k = np.stack([m[:, 1] * dirn[:, 2] - m[:, 2] * dirn[:, 1],
+                  m[:, 2] * dirn[:, 0] - m[:, 0] * dirn[:, 2],
+                  m[:, 0] * dirn[:, 1] - m[:, 1] * dirn[:, 0]], 1)
+    q = k[:, 0] * k[:, 0] + k[:, 1] * k[:, 1] + k[:, 2] * k[:, 2]
+    md = m[:, 0] * dirn[:, 0] + m[:, 1] * dirn[:, 1] + m[:, 2] * dirn[:, 2]
+    rej = (q > rho2) | ((md - rho) > best * f(1.000002)) | ((md + rho) < 0)
+    wild = ~(np.abs(org) <= extent).all(1)
+    return ~rej | wild
+
+
+def normalize32(d):
+    """Ray::Ray: dir * (1 / sqrt(dot)) in float32 (Ray.cu:2, helper_math.h:62-65,1309)."""
+    f = np.float32
+    dd = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+    inv = f(1.0) / np.sqrt(dd, dtype=f)
+    return (d * inv[:, None]).astype(f)
+
+
+def random_triangle(rng, kind):
+    c = rng.uniform(-300, 300, 3)
+    if kind == "tiny":
+        s = rng.uniform(0.05, 0.3)
+    elif kind == "large":
+        s = rng.uniform(30, 200)
+    else:
+        s = rng.uniform(0.5, 8)
+    a = c + rng.normal(size=3) * s
+    b = c + rng.normal(size=3) * s
+    d = c + rng.normal(size=3) * s
+    if kind == "sliver":
+        d = a + (b - a) * rng.uniform(0.2, 0.8) + rng.normal(size=3) * s * 0.01
+    return np.array([a, b, d], np.float32)
+
+
+@pytest.mark.parametrize("kind", ["normal", "tiny", "large", "sliver"])
+def test_accepted_pairs_pass_the_sphere_test(kind):
+    rng = np.random.default_rng({"normal": 1, "tiny": 2, "large": 3, "sliver": 4}[kind])
+    n_accept = 0
+    for _ in range(60):
+        tri = random_triangle(rng, kind)
+        b = SceneBuilder()
+        b.add_triangle(tri, [(0, 0, 1)] * 3, identity(), (0.7, 0.7, 0.7))
+        scene = b.build()
+        bounds, pos, ext = abi.host_bounds(scene)
+        assert pos[0] == 0
+        # targets: inside, on the edges, and in a band just outside them (the "fat" rim)
+        n = 3000
+        w = rng.dirichlet([1, 1, 1], n)
+        w[n // 3:] = rng.dirichlet([1, 1, 0.02], n - n // 3)           # hug an edge
+        w = w[np.arange(n)[:, None], rng.permuted(np.tile(np.arange(3), (n, 1)), axis=1)]
+        tgt = (w[:, :, None] * tri[None].astype(np.float64)).sum(1)
+        edge = np.linalg.norm(tri[1] - tri[0]) + 1e-9
+        tgt += rng.normal(size=(n, 3)) * rng.choice([0.0, 1e-4, 1e-3, 1e-2, 0.1], (n, 1)) / max(edge, 0.05)
+        org = (tgt + rng.normal(size=(n, 3)) * rng.choice([2.0, 40.0, 600.0], (n, 1))).astype(np.float32)
+        d = (tgt - org.astype(np.float64)).astype(np.float32)
+        t, pid, hit = orc.scene_hit(scene, org, d)
+        acc = pid == 0
+        if not acc.any():
+            continue
+        n_accept += int(acc.sum())
+        ok = node_pass(bounds[0], org[acc], normalize32(d[acc]), ext)
+        assert ok.all(), f"{(~ok).sum()} accepted pairs would be culled (rho={bounds[0][3]})"
+        # the depth test at the moment of acceptance: best just above the accepted t
+        ok2 = node_pass(bounds[0], org[acc], normalize32(d[acc]), ext, best=np.nextafter(t[acc], np.float32(2e6)))
+        assert ok2.all()
+    assert n_accept > (200 if kind != "tiny" else 0)
+
+
+def test_invisible_triangles_are_marked():
+    """H1: 2*area below 0.01 can never pass Model.cu:99 -> rho = -inf (always culled)."""
+    b = SceneBuilder()
+    b.add_triangle([(0, 0, -5), (0.05, 0, -5), (0, 0.05, -5)], [(0, 0, 1)] * 3, identity(), (0.7,) * 3)
+    b.add_triangle([(0, 0, -5), (2, 0, -5), (0, 2, -5)], [(0, 0, 1)] * 3, identity(), (0.7,) * 3)
+    bounds, pos, ext = abi.host_bounds(b.build())
+    assert bounds[0][3] == -np.inf and np.isfinite(bounds[1][3]) and bounds[1][3] > 1.0
+    assert sorted(pos.tolist()) == [0, 1]
+
+
+def test_position_is_a_permutation():
+    from raytracer_amd import scenes
+    cfg = scenes.c3(64, 36, lon=20, lat=20, ground=(6, 3))
+    bounds, pos, ext = abi.host_bounds(cfg.scene)
+    assert sorted(pos.tolist()) == list(range(cfg.scene.n_tris))
+    assert np.isfinite(bounds[:, 3]).all() and ext >= 125.0

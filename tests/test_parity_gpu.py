@@ -83,6 +83,80 @@ def test_scene_hit_mixed(gpu_ctx_factory):
     assert 0.2 < hit.mean() < 1.0 and len(np.unique(pid)) > 50
 
 
+def soup_scene(rng, n_tris):
+    """Unordered triangle soup: sizes from invisible (H1) to huge, slivers, duplicates (exact
+    ties in t), coplanar pairs; plus two spheres.  Index order is spatially random, so the
+    device order (Morton) differs from the reference order everywhere."""
+    b = SceneBuilder()
+    P = []
+    for i in range(n_tris):
+        c = rng.uniform([-250, -150, -700], [250, 200, -200])
+        s = rng.choice([0.03, 1.0, 6.0, 40.0, 160.0], p=[0.05, 0.3, 0.4, 0.2, 0.05])
+        a, bb, d = (c + rng.normal(size=3) * s for _ in range(3))
+        if i % 17 == 0:
+            d = a + (bb - a) * 0.5 + rng.normal(size=3) * s * 0.02          # sliver
+        P.append(np.array([a, bb, d], np.float32))
+    for i in range(0, n_tris, 11):                                           # exact duplicates
+        P[(i + 5) % n_tris] = P[i].copy()
+    P = np.stack(P)
+    N = np.broadcast_to(np.float32([0, 0, 1]), P.shape).copy()
+    b.add_triangle(P[0], N[0], identity(), (0.7, 0.6, 0.5))
+    b.add_triangle(P[1], N[1], translation(3, -2, 5), (0.5, 0.6, 0.7))
+    h = (n_tris - 2) // 2
+    b.add_mesh(P[2:2 + h], N[2:2 + h], identity(), (0.7, 0.7, 0.7))
+    b.add_mesh(P[2 + h:], N[2 + h:], identity(), (0.6, 0.7, 0.6))
+    b.add_sphere(1.0 / 35.0, translation(-60.0, 10.0, -420.0), (0.7, 0.2, 0.1))
+    b.add_sphere(1.0 / 20.0, translation(90.0, -40.0, -300.0), (0.3, 0.3, 0.8))
+    b.add_point_light((-300.0, 300.0, -100.0), (3.0e5, 2.5e5, 2.0e5))
+    b.add_point_light((250.0, 150.0, -200.0), (1.0e5, 1.5e5, 2.0e5))
+    return b.build()
+
+
+@pytest.mark.parametrize("n_tris,seed", [(5, 11), (300, 12), (4000, 13)])
+def test_culling_is_results_identical(gpu_ctx_factory, n_tris, seed):
+    """Sphere-tree traversal == scan of every triangle == oracle, bit for bit, on a soup
+    with ties, slivers and invisible triangles; rays from inside and far outside the scene
+    (the far ones exceed the culling extent and take the unculled path)."""
+    rng = np.random.default_rng(seed)
+    scene = soup_scene(rng, n_tris)
+    ctx = gpu_ctx_factory(16, 16)
+    ctx.upload_scene(scene)
+    n = 30000
+    org = rng.uniform([-300, -200, -750], [300, 250, 100], (n, 3)).astype(np.float32)
+    org[:200] *= 50.0                                   # far outside: "wild" rays
+    tgt = rng.uniform([-250, -150, -700], [250, 200, -200], (n, 3)).astype(np.float32)
+    d = tgt - org
+    rt, rpid, rhit = orc.scene_hit(scene, org, d)
+    for cull in (1, 0):
+        ctx.set_culling(cull)
+        t, pid, hit = ctx.scene_hit(org, d)
+        assert np.array_equal(pid, rpid), f"cull={cull}: {(pid != rpid).sum()} ids differ"
+        assert np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+        assert np.array_equal(hit, rhit)
+    ctx.set_culling(1)
+    assert hit.mean() > (0.3 if n_tris >= 300 else 0.01)
+
+
+def test_culling_render_equals_scan(gpu_ctx_factory):
+    """Whole render (primary + shadow + bounces) with and without culling: identical bits."""
+    scene = soup_scene(np.random.default_rng(21), 1500)
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    ctx = gpu_ctx_factory(96, 64)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    out = []
+    for cull in (1, 0):
+        ctx.set_culling(cull)
+        ctx.reset()
+        ctx.render(2, 3)
+        out.append(ctx.read_framebuffer())
+    ctx.set_culling(1)
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    ref = orc.render(scene, cam, 96, 64, spp=2, max_depth=3)
+    check_images(out[0], ref)
+
+
 @pytest.mark.parametrize("depth,spp", [(0, 1), (0, 3), (12, 2)])
 def test_c1_sphere(gpu_ctx_factory, depth, spp):
     cfg = scenes.c1(160, 120)

@@ -152,15 +152,15 @@ int rt_postprocess(rt_context *ctx, float *hdr_rgba, float *filtered_rgba);
 
 /* No counterpart in the reference, whose Scene::hit is a plain scan ("Brute force
  * method", Scene/Scene.cu:7).  enabled = 1 (default): the closest-hit kernel skips
- * groups of triangles whose conservative bounding sphere no ray of the wave can hit;
+ * groups of triangles whose conservative bounding box no ray of the wave can hit;
  * the result is the scan's, bit for bit.  enabled = 0: every ray is tested
  * against every triangle -- the validation mode the parity tests compare against. */
 int rt_set_culling(rt_context *ctx, int enabled);
 
 /* Host-only view of what rt_upload_scene derives for the culling (no device needed; for
- * tests and tools): per triangle, in the reference's traversal order, its conservative
- * bounding sphere bounds[n_tris][4] = (cx, cy, cz, rho) and its position in the device
- * order; geom_extent = max |coordinate| of the geometry.  Any pointer may be NULL. */
+ * tests and tools): per triangle, in the reference's traversal order, the conservative
+ * box of its acceptance region bounds[n_tris][6] = (lo.xyz, hi.xyz) and its position in
+ * the device order; geom_extent = max |coordinate| of the geometry.  Any pointer may be NULL. */
 int rt_host_bounds(const rt_scene_desc *scene, float *bounds, int32_t *position,
                    float *geom_extent);
 

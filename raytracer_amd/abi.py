@@ -212,9 +212,9 @@ def partition_pixels(width, height, rank, world, tile=64):
 
 
 def host_bounds(scene: SceneData):
-    """(bounds[n,4], position[n], geom_extent) of rt_host_bounds: host-only."""
+    """(bounds[n,6] = lo.xyz hi.xyz, position[n], geom_extent) of rt_host_bounds: host-only."""
     d = scene.desc()
-    b = np.zeros((scene.n_tris, 4), np.float32)
+    b = np.zeros((scene.n_tris, 6), np.float32)
     pos = np.zeros(scene.n_tris, np.int32)
     ext = C.c_float()
     rc = lib().rt_host_bounds(C.byref(d), _fp(b), _ip(pos), C.byref(ext))

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@ struct rt_context {
     int max_blocks = 2048;
 
     DevView v{};
+    uint32_t isect_seq = 0;              // closest-hit launches so far (dispenser parity)
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
 
     // stats
@@ -243,24 +245,20 @@ void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, ui
         e1 = next_event(c);
     }
     if (e0) (void)hipEventRecord(e0, c->stream);
-    launch_intersect(c->stream, c->v, q, count, cap, out_t, out_id, c->max_blocks);
+    launch_intersect(c->stream, c->v, q, count, cap, out_t, out_id, c->max_blocks,
+                     &c->v.ctl->work[c->isect_seq & 1u], &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
+    c->isect_seq++;
     if (e1) (void)hipEventRecord(e1, c->stream);
     c->launches++;
 }
 
-// Culling extent: ray origins inside [-extent, extent]^3 (camera and every hit point)
-// are culled with `slack` covering the fp32 error of p = o + t d and of the sphere
-// tests at that coordinate magnitude; other rays are scanned unculled.
+// Culling extent: rays whose origin lies inside [-extent, extent]^3 (the camera and
+// every hit point of an ordinary scene) are culled; the boxes carry the fp32 slack of
+// p = o + t d for coordinates up to that magnitude (rt_upload.cpp).  Other rays are
+// tested against every live triangle.
 void update_extent(rt_context *c)
 {
-    float e = std::max(c->geom_extent, 1.0f);
-    if (c->have_cam) {
-        const v3 &p = c->v.cam.pos;
-        float m = std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z)));
-        if (std::isfinite(m)) e = std::max(e, m);
-    }
-    c->v.tree.extent = 4.0f * e;
-    c->v.tree.slack = c->v.tree.extent * (1.0f / 131072.0f);      // 2 * 2^-18 * extent
+    c->v.tree.extent = kCullExtent * std::max(c->geom_extent, 1.0f);
 }
 
 } // namespace
@@ -289,6 +287,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     c->v.width = width;
     c->v.height = height;
     c->v.cull = 1;
+    if (const char *e = std::getenv("RT_ISECT_PAIRS")) c->v.isect_pairs = std::atoi(e);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_r0);
@@ -344,11 +343,11 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     DevView &v = c->v;
     TriRec *tris = nullptr; TriCold *cold = nullptr; ModelRec *models = nullptr;
     SphereRec *spheres = nullptr; LightRec *lights = nullptr;
-    NodeRec *nodes = nullptr; uint32_t *pos_of = nullptr;
+    NodeGroup *nodes = nullptr; uint32_t *pos_of = nullptr;
     if ((rc = dalloc(c, c->scene_allocs, tris, hs.tris.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, cold, hs.cold.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, pos_of, hs.pos_of.size()))) return rc;
-    if ((rc = dalloc(c, c->scene_allocs, nodes, hs.nodes.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, nodes, hs.groups.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, models, hs.models.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, spheres, hs.spheres.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, lights, hs.lights.size()))) return rc;
@@ -358,7 +357,7 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     RT_HIP(c, up(tris, hs.tris.data(), hs.tris.size() * sizeof(TriRec)));
     RT_HIP(c, up(cold, hs.cold.data(), hs.cold.size() * sizeof(TriCold)));
     RT_HIP(c, up(pos_of, hs.pos_of.data(), hs.pos_of.size() * sizeof(uint32_t)));
-    RT_HIP(c, up(nodes, hs.nodes.data(), hs.nodes.size() * sizeof(NodeRec)));
+    RT_HIP(c, up(nodes, hs.groups.data(), hs.groups.size() * sizeof(NodeGroup)));
     RT_HIP(c, up(models, hs.models.data(), hs.models.size() * sizeof(ModelRec)));
     RT_HIP(c, up(spheres, hs.spheres.data(), hs.spheres.size() * sizeof(SphereRec)));
     RT_HIP(c, up(lights, hs.lights.data(), hs.lights.size() * sizeof(LightRec)));
@@ -367,10 +366,11 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     v.n_tris = (int)hs.cold.size();
     v.n_spheres = (int)hs.spheres.size();
     v.n_lights = (int)hs.lights.size();
+    v.tree.groups = nodes;
     for (int l = 0; l < kMaxLevels; l++)
-        v.tree.level[l] = nodes + hs.level_off[std::min<size_t>((size_t)l, hs.level_off.size() - 1)];
+        v.tree.level_off[l] = (uint32_t)hs.level_off[std::min<size_t>((size_t)l, hs.level_off.size() - 1)];
     v.tree.top = hs.top;
-    v.tree.n_groups0 = (int)(hs.level_cnt[0] / kTreeArity);
+    v.tree.n_groups0 = (int)hs.level_cnt[0];
     c->geom_extent = hs.geom_extent;
     update_extent(c);
     c->n_lights = v.n_lights;
@@ -575,7 +575,10 @@ extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float 
         if (e == hipSuccess) e = hipMemcpyAsync(d_count, &un, 4, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
             launch_prepare_rays(s, q, d_org, d_dir, un);
-            launch_intersect(s, c->v, q, d_count, un, d_t, d_id, c->max_blocks);
+            launch_intersect(s, c->v, q, d_count, un, d_t, d_id, c->max_blocks,
+                             &c->v.ctl->work[c->isect_seq & 1u],
+                             &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
+            c->isect_seq++;
             launch_ishit(s, d_t, d_hit, un);
             e = hipStreamSynchronize(s);
         }
@@ -650,12 +653,14 @@ extern "C" int rt_host_bounds(const rt_scene_desc *d, float *bounds, int32_t *po
     if (rc != RT_OK) return fail(nullptr, rc, err);
     const size_t n = hs.cold.size();
     for (size_t g = 0; g < n; g++) {
-        const NodeRec &r = hs.nodes[hs.level_off[0] + hs.pos_of[g]];
-        if (bounds) {
-            bounds[4 * g + 0] = r.cx; bounds[4 * g + 1] = r.cy;
-            bounds[4 * g + 2] = r.cz; bounds[4 * g + 3] = r.rho;
-        }
-        if (position) position[g] = (int32_t)hs.pos_of[g];
+        const uint32_t pos = hs.pos_of[g];
+        const NodeGroup &G = hs.groups[hs.level_off[0] + pos / kTreeArity];
+        if (bounds)
+            for (int a = 0; a < 3; a++) {
+                bounds[6 * g + a] = G.lo[a][pos % kTreeArity];
+                bounds[6 * g + 3 + a] = G.hi[a][pos % kTreeArity];
+            }
+        if (position) position[g] = (int32_t)pos;
     }
     if (geom_extent) *geom_extent = hs.geom_extent;
     return RT_OK;

@@ -137,6 +137,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct RayPair {
     f2 ox, oy, oz, dx, dy, dz;
+    f2 ix, iy, iz;    // 1 / d per axis (|d| clamped away from 0) for the box tests only
     f2 best;          // running closest t per ray (IntersectRecord::t)
     f2 bestp;         // best * (1 + 2^-19): conservative side of every pre-test
     int idx, idy;     // reference traversal index of the closest primitive, -1 = none
@@ -145,24 +146,40 @@ struct RayPair {
 
 constexpr float kBestInfl = 1.000002f;
 constexpr float kEpsDefl = kEps * 0.999999f;
+constexpr float kTnDefl = 0.999998f;
 
-// Conservative test of one bounding sphere (centre c, radius rho, rho2 >= rho^2)
-// against both rays: true = some triangle below the node may still be accepted.
-//   line:   |(c - o) x d|^2 > rho^2              -> the ray's line misses the sphere
-//   depth:  (c - o).d - rho > best (inflated)    -> the sphere starts beyond the closest hit
-//   behind: (c - o).d + rho < 0                  -> the sphere lies behind the origin
-__device__ __forceinline__ void node_test(const RayPair &r, float cx, float cy, float cz, float rho,
-                                          float rho2, bool &px, bool &py)
+// 1 / d for the slab test.  A component below 1e-30 in magnitude is replaced by +-1e-30:
+// over the t range of the path (t < 1e6) that moves the ray by less than 1e-24, far
+// inside the slack the boxes carry, and keeps every product finite (no 0 * inf).
+__device__ __forceinline__ float slab_inv(float d)
 {
-    f2 mx = cx - r.ox, my = cy - r.oy, mz = cz - r.oz;
-    f2 kx = my * r.dz - mz * r.dy, ky = mz * r.dx - mx * r.dz, kz = mx * r.dy - my * r.dx;
-    f2 q = kx * kx + ky * ky + kz * kz;
-    f2 md = mx * r.dx + my * r.dy + mz * r.dz;
-    f2 near = md - rho, far = md + rho;
-    bool rx = (q.x > rho2) | (near.x > r.bestp.x) | (far.x < 0.0f);
-    bool ry = (q.y > rho2) | (near.y > r.bestp.y) | (far.y < 0.0f);
-    px = !rx | r.wildx;
-    py = !ry | r.wildy;
+    float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;
+    return 1.0f / a;
+}
+
+// Conservative slab test of one box against both rays: true = some triangle below the
+// node may still be accepted.  [tn, tf] is the parameter interval of o + t d inside
+// the box; the node is skipped when it is empty, ends behind the origin, or starts
+// beyond the closest hit so far (best, inflated).  The factor on tf covers the
+// rounding of the six products (a few ulp each).  `ex`, `ey` return the entry
+// parameter, which orders the traversal.
+__device__ __forceinline__ void node_test(const RayPair &r, float lx, float ly, float lz, float hx,
+                                          float hy, float hz, bool &px, bool &py, float &ex,
+                                          float &ey)
+{
+    f2 ax = (lx - r.ox) * r.ix, bx = (hx - r.ox) * r.ix;
+    f2 ay = (ly - r.oy) * r.iy, by = (hy - r.oy) * r.iy;
+    f2 az = (lz - r.oz) * r.iz, bz = (hz - r.oz) * r.iz;
+    float tnx = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), 0.0f));
+    float tny = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), 0.0f));
+    float tfx = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
+    float tfy = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+    tfx = fminf(tfx * kBestInfl, r.bestp.x);
+    tfy = fminf(tfy * kBestInfl, r.bestp.y);
+    px = !(tnx * kTnDefl > tfx) | r.wildx;
+    py = !(tny * kTnDefl > tfy) | r.wildy;
+    ex = tnx;
+    ey = tny;
 }
 
 // Triangle::hit (Model/Model.cu:91-137) for both rays of a pair against one

@@ -14,6 +14,10 @@ struct Ctl {
     uint32_t n_next;       // survivors pushed for the next bounce
     uint32_t n_shadow;     // shadow rays pushed by the current light pass
     uint32_t pad;
+    // Chunk dispensers of the closest-hit kernel (one per launch parity): waves draw
+    // 64*R-ray chunks with atomicAdd; launch k uses work[k & 1] and zeroes the other.
+    uint32_t work[2];
+    uint32_t pad2[2];
     unsigned long long shadow_total;   // shadow rays cast since rt_reset_stats
     unsigned long long bounce_total;   // bounce (>= 1) rays traced since rt_reset_stats
 };
@@ -24,15 +28,15 @@ struct RayQueue {
     uint32_t *path;        // local path (pixel) index; unused for shadow queues
 };
 
-// Implicit 4-ary bounding-sphere tree over the triangle records (rt_math.h NodeRec;
-// built by rt_upload.cpp).  Children of node i of level l+1 are nodes 4i..4i+3 of
-// level l, so a child group is one aligned 64-byte block: no pointers, no stack.
+// Implicit 4-ary box tree over the triangle records (rt_math.h NodeGroup; built by
+// rt_upload.cpp).  The children of node i of level l+1 are the four boxes of group i
+// of level l: no pointers, no stack.
 struct TreeView {
-    const NodeRec *level[kMaxLevels];
-    int top;               // the top level holds one group of at most 4 nodes
+    const NodeGroup *groups;          // all levels back to back
+    uint32_t level_off[kMaxLevels];   // first group of level l in `groups`
+    int top;               // the top level is one group
     int n_groups0;         // number of 4-triangle groups of level 0
     float extent;          // rays whose origin leaves [-extent, extent]^3 are never culled
-    float slack;           // added to every rho: fp32 error of the ray-side arithmetic
 };
 
 struct DevView {
@@ -45,6 +49,7 @@ struct DevView {
     const TriCold *tri_cold;        // reference traversal order
     TreeView tree;
     int cull;                       // 0: scan every triangle (validation), 1: use the tree
+    int isect_pairs;                // ray pairs per lane in k_intersect: 1, 2, or 0 = by queue size
     const ModelRec *models;
     const SphereRec *spheres;
     const LightRec *lights;
@@ -78,7 +83,8 @@ void launch_ctl_after_shadow(hipStream_t s, Ctl *ctl);
 void launch_ctl_next_bounce(hipStream_t s, Ctl *ctl);
 void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n);
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
-                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks);
+                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks,
+                      uint32_t *work, uint32_t *work_next);
 void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
                   int nl, int n_lights_total, int max_blocks);
 void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,

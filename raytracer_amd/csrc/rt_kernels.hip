@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t
 // wave-uniform: node and triangle records come through the scalar data path, one
 // aligned 64-byte block (s_load_dwordx16) per group of four nodes / per triangle, and
 // sit in SGPRs as operands of packed fp32 VALU ops.  Traversal of the implicit 4-ary
-// sphere tree is stackless: the state is (level, group index, 4 pending-child bits per
+// box tree is stackless: the state is (level, group index, 4 pending-child bits per
 // level packed in one 64-bit scalar), all in SGPRs; a group is expanded when any ray
 // of the wave may still hit below it.  The tests of node_test() only ever discard
 // (ray, triangle) pairs Triangle::hit would reject, so the result is the scan's.
@@ -98,20 +98,52 @@ __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, u
     }
 }
 
+// Per-level traversal state lives in ONE VGPR: lane l holds level l's word
+// (bits 0-7: the passing children still to visit, nearest first, 2 bits each;
+// bits 8-10: how many), read with v_readlane at a wave-uniform lane index and
+// written with a lane-id select.  Level offsets sit in a second VGPR the same way, so
+// descending costs no memory access besides the node block itself.
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int l)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+__device__ __forceinline__ uint32_t lane_set(uint32_t v, int l, uint32_t x)
+{
+    return (threadIdx.x & 63u) == (uint32_t)l ? x : v;     // v_cmp + v_cndmask
+}
+__device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
+{
+    uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+
 template <int P, bool CULL>
 __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec *__restrict__ tris,
                                                       const SphereRec *__restrict__ spheres,
                                                       int n_tris, int n_spheres, RayQueue q,
                                                       const uint32_t *__restrict__ count_ptr,
                                                       float *__restrict__ out_t,
-                                                      int32_t *__restrict__ out_id)
+                                                      int32_t *__restrict__ out_id,
+                                                      uint32_t *__restrict__ work,
+                                                      uint32_t *__restrict__ work_next)
 {
     constexpr uint32_t R = 2 * P;
     const uint32_t count = *count_ptr;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
-    for (uint32_t base = wave * 64u * R; base < count; base += n_waves * 64u * R) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *work_next = 0u;                 // the next launch's dispenser (stream-ordered after us)
+    const uint32_t lvloff = tv.level_off[lane & (kMaxLevels - 1)];
+    // Chunks cost anything from a handful of node tests (rays into empty space) to
+    // thousands, so waves draw them from a dispenser instead of striding the queue.
+    // Every wave leaves as soon as it draws a chunk past the end.
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0)
+            chunk = atomicAdd(work, 1u);
+        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        if ((unsigned long long)chunk * (64u * R) >= count)
+            break;
+        const uint32_t base = chunk * 64u * R;
         WaveRays<P> w;
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -133,6 +165,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
             }
             r.ox = f2{o0[0], o1[0]}; r.oy = f2{o0[1], o1[1]}; r.oz = f2{o0[2], o1[2]};
             r.dx = f2{d0[0], d1[0]}; r.dy = f2{d0[1], d1[1]}; r.dz = f2{d0[2], d1[2]};
+            r.ix = f2{slab_inv(d0[0]), slab_inv(d1[0])};
+            r.iy = f2{slab_inv(d0[1]), slab_inv(d1[1])};
+            r.iz = f2{slab_inv(d0[2]), slab_inv(d1[2])};
             r.best = f2{b0, b1};
             r.bestp = r.best * kBestInfl;
             r.idx = -1; r.idy = -1;
@@ -146,46 +181,61 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
         if (CULL) {
             int l = tv.top;
             uint32_t g = 0;
-            unsigned long long pending = 0;      // 4 child bits per level
+            uint32_t state = 0;                  // lane l: pending children of level l
             uint32_t lanebits = 0;               // level 0: which (triangle, ray) pairs passed
             bool expand = true;
             for (;;) {
                 if (expand) {
-                    const NodeRec *grp = tv.level[l] + (size_t)g * kTreeArity;
-                    const NodeRec n0 = grp[0], n1 = grp[1], n2 = grp[2], n3 = grp[3];
-                    const NodeRec nn[4] = {n0, n1, n2, n3};
-                    uint32_t m = 0, lb = 0;
+                    const NodeGroup G = tv.groups[lane_get(lvloff, l) + g];
+                    uint32_t key[4], lb = 0, n_pass = 0;
 #pragma unroll
                     for (int j = 0; j < kTreeArity; j++) {
-                        float rho = nn[j].rho + tv.slack, rho2 = rho * rho;
                         bool any = false;
+                        float near = 3.0e38f;    // smallest entry parameter among this lane's passing rays
 #pragma unroll
                         for (int p = 0; p < P; p++) {
                             bool px, py;
-                            node_test(w.r[p], nn[j].cx, nn[j].cy, nn[j].cz, rho, rho2, px, py);
+                            float ex, ey;
+                            node_test(w.r[p], G.lo[0][j], G.lo[1][j], G.lo[2][j], G.hi[0][j], G.hi[1][j],
+                                      G.hi[2][j], px, py, ex, ey);
                             any |= px | py;
+                            near = fminf(near, fminf(px ? ex : 3.0e38f, py ? ey : 3.0e38f));
                             lb |= ((uint32_t)px << (j * 2 * P + 2 * p)) | ((uint32_t)py << (j * 2 * P + 2 * p + 1));
                         }
-                        // rho = -inf (padding, or a triangle Model.cu:99 always rejects) is
-                        // dead for every ray, including the unculled ones
-                        if (__ballot(any) && nn[j].rho > -__builtin_huge_valf())
-                            m |= 1u << j;
+                        // lo > hi (padding, or a triangle Model.cu:99 always rejects) is dead
+                        // for every ray, including the unculled ones
+                        unsigned long long b = __ballot(any);
+                        key[j] = 0xffffffffu;
+                        if (b && !(G.lo[0][j] > G.hi[0][j])) {
+                            // visit order: entry parameter of the first passing lane (a coherent
+                            // wave's rays agree on it closely enough); the child index rides in
+                            // the two low mantissa bits
+                            float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                __builtin_bit_cast(int, near), __builtin_ctzll(b)));
+                            key[j] = (__builtin_bit_cast(uint32_t, e) & ~3u) | (uint32_t)j;
+                            n_pass++;
+                        }
                     }
-                    pending |= (unsigned long long)m << (4 * l);
+                    cswap(key[0], key[1]); cswap(key[2], key[3]);
+                    cswap(key[0], key[2]); cswap(key[1], key[3]);
+                    cswap(key[1], key[2]);
+                    uint32_t word = (key[0] & 3u) | (key[1] & 3u) << 2 | (key[2] & 3u) << 4 |
+                                    (key[3] & 3u) << 6 | n_pass << 8;
+                    state = lane_set(state, l, word);
                     if (l == 0)
                         lanebits = lb;
                     expand = false;
                 }
-                uint32_t m = (uint32_t)(pending >> (4 * l)) & 15u;
-                if (m == 0) {
+                uint32_t word = lane_get(state, l);
+                if ((word >> 8) == 0) {
                     if (l == tv.top)
                         break;
                     l++;
                     g >>= 2;
                     continue;
                 }
-                int j = __builtin_ctz(m);
-                pending &= ~(1ull << (4 * l + j));
+                int j = (int)(word & 3u);
+                state = lane_set(state, l, ((word & 0xffu) >> 2) | ((word >> 8) - 1u) << 8);
                 uint32_t node = g * kTreeArity + (uint32_t)j;
                 if (l == 0) {
                     test_triangle<P>(tris, node, w, lanebits, j);
@@ -614,17 +664,18 @@ void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n)
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
-                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks)
+                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks,
+                      uint32_t *work, uint32_t *work_next)
 {
     // 4 rays per lane when that still leaves every SIMD several waves, else 2
-    const bool wide = capacity >= (1u << 20);
+    const bool wide = v.isect_pairs ? v.isect_pairs == 2 : capacity >= (1u << 20);
     const uint32_t rays_per_block = kBlock * (wide ? 4u : 2u);
     uint32_t g = (capacity + rays_per_block - 1) / rays_per_block;
     if (g < 1) g = 1;
     if ((int)g > max_blocks) g = (uint32_t)max_blocks;
 #define RT_LAUNCH_INTERSECT(P, CULL)                                                           \
     k_intersect<P, CULL><<<g, kBlock, 0, s>>>(v.tree, v.tris, v.spheres, v.n_tris, v.n_spheres, \
-                                              q, count, out_t, out_id)
+                                              q, count, out_t, out_id, work, work_next)
     if (v.cull) {
         if (wide) RT_LAUNCH_INTERSECT(2, true); else RT_LAUNCH_INTERSECT(1, true);
     } else {

@@ -168,14 +168,20 @@ struct TriRec {
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
-// Conservative bounding sphere of everything Triangle::hit can accept for one triangle
-// (leaf) or for four children (inner node): centre and radius, 16 bytes.  A ray whose
-// line misses the sphere, or whose reach [0.01, best) along the ray misses it, cannot
-// be accepted by any triangle below the node (derivation in DESIGN.md, "Culling is
-// results-identical").  rho = -inf: nothing below can ever be hit; +inf: never culled.
-struct NodeRec { float cx, cy, cz, rho; };
-static_assert(sizeof(NodeRec) == 16, "NodeRec must be 16 bytes");
+// Conservative axis-aligned bounds of everything Triangle::hit can accept, four nodes
+// per record in struct-of-arrays form (96 bytes = one s_load_dwordx16 + one
+// s_load_dwordx8): lo[axis][child], hi[axis][child].  Leaves (level 0) bound one
+// triangle's acceptance region each -- the triangle's box grown by the distance
+// `delta` within which the area test of Model.cu:113 can still pass, plus the fp32
+// slack of p = o + t d; inner nodes are exact unions.  A ray whose parameter interval
+// inside the box misses (0, best) cannot be accepted by any triangle below the node
+// ("Culling is results-identical").  lo > hi: dead (padding, or a triangle
+// Model.cu:99 rejects for every ray); lo = -inf, hi = +inf: never culled.
+struct NodeGroup { float lo[3][4]; float hi[3][4]; };
+static_assert(sizeof(NodeGroup) == 96, "NodeGroup must be 96 bytes");
 
+constexpr float kCullExtent = 16.0f; // rays are culled while their origin stays inside
+                                     // [-E, E]^3, E = kCullExtent * max |scene coordinate|
 constexpr int kTreeArity = 4;        // children per node = one 64-byte scalar load
 constexpr int kMaxLevels = 16;       // 4^16 leaves
 

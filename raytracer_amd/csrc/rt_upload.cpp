@@ -58,59 +58,63 @@ static void build_tri(const rt_scene_desc *d, int g, TriRec &T, TriCold &C)
 
 // ------------------------------------------------------------------ culling bounds
 // Everything below runs in double on the float values the kernels will see; results
-// are rounded UP to float.  DESIGN.md ("Culling is results-identical") has the proof
-// sketch; the short form:
+// are rounded OUTWARD to float.  DESIGN.md ("Culling is results-identical") has the
+// argument; the short form:
 //   Triangle::hit accepts a point p only if fl(s1+s2+s3) - S <= 0.001 (Model.cu:113).
 //   In exact arithmetic s1+s2+s3 - S = 2 * sum over edges p lies outside of
 //   (edge length * distance to the edge line) for p in the plane, and grows like
 //   sqrt(S^2 + P^2 h^2) - S with the height h above it.  With x = 0.001 + the fp32
 //   evaluation error, p must therefore lie within
 //       delta = x / k + sqrt(2 S x + x^2) / P,   k = 2 e_min sin(theta_min / 2)
-//   of the triangle, hence within r0 + delta of the centre of its enclosing circle.
+//   of the triangle, hence inside the triangle's bounding box grown by delta.
 namespace {
 
-struct Bound { double c[3]; double rho; };
+struct Box { double lo[3], hi[3]; };      // lo > hi: dead; (-inf, +inf): never culled
 const double kInfD = std::numeric_limits<double>::infinity();
+const Box kDeadBox = {{kInfD, kInfD, kInfD}, {-kInfD, -kInfD, -kInfD}};
+const Box kOpenBox = {{-kInfD, -kInfD, -kInfD}, {kInfD, kInfD, kInfD}};
 
 inline double len3(const double *v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-inline double dist3(const double *a, const double *b)
-{
-    double d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
-    return len3(d);
-}
 inline void cross3d(const double *a, const double *b, double *r)
 {
     r[0] = a[1] * b[2] - a[2] * b[1];
     r[1] = a[2] * b[0] - a[0] * b[2];
     r[2] = a[0] * b[1] - a[1] * b[0];
 }
+inline float round_dn(double v)
+{
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
 inline float round_up(double v)
 {
-    if (!(v == v)) return std::numeric_limits<float>::infinity();
     float f = (float)v;
     if ((double)f < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
     return f;
 }
 
-Bound leaf_bound(const TriRec &T)
+// Box of one triangle's acceptance region, WITHOUT the coordinate-magnitude slack
+// (added by build_tree once the extent of the whole scene is known).
+Box leaf_box(const TriRec &T)
 {
-    Bound B{{0.0, 0.0, 0.0}, kInfD};
     const double a[3] = {T.ax, T.ay, T.az}, b[3] = {T.bx, T.by, T.bz}, c[3] = {T.cx, T.cy, T.cz};
     const double n1 = std::fabs((double)T.nx) + std::fabs((double)T.ny) + std::fabs((double)T.nz);
     for (int i = 0; i < 3; i++)
-        if (!std::isfinite(a[i]) || !std::isfinite(b[i]) || !std::isfinite(c[i])) return B;
-    if (!std::isfinite(n1) || !std::isfinite((double)T.S)) return B;
+        if (!std::isfinite(a[i]) || !std::isfinite(b[i]) || !std::isfinite(c[i])) return kOpenBox;
+    if (!std::isfinite(n1) || !std::isfinite((double)T.S)) return kOpenBox;
     // |dot(norma, dir)| <= |norma|_1 (1 + ulps) < 0.01: Model.cu:99 rejects every ray (H1)
-    if (n1 * 1.00001 < 0.01) { B.rho = -kInfD; return B; }
+    if (n1 * 1.00001 < 0.01) return kDeadBox;
     double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     double v[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
     double w[3] = {c[0] - b[0], c[1] - b[1], c[2] - b[2]};
     double eab = len3(u), eca = len3(v), ebc = len3(w);
-    double emin = std::min(eab, std::min(eca, ebc)), P = eab + eca + ebc;
+    double emin = std::min(eab, std::min(eca, ebc)), emax = std::max(eab, std::max(eca, ebc));
+    double P = eab + eca + ebc;
     double cr[3];
     cross3d(u, v, cr);
     double Sd = len3(cr);
-    if (!(emin > 0.0) || !(Sd > 0.0)) return B;
+    if (!(emin > 0.0) || !(Sd > 0.0)) return kOpenBox;
     // smallest vertex angle, from the law of cosines
     auto ang = [](double opp, double s1, double s2) {
         double cs = (s1 * s1 + s2 * s2 - opp * opp) / (2.0 * s1 * s2);
@@ -118,81 +122,29 @@ Bound leaf_bound(const TriRec &T)
     };
     double th = std::min(ang(ebc, eab, eca), std::min(ang(eca, eab, ebc), ang(eab, eca, ebc)));
     double k = 2.0 * emin * std::sin(0.5 * th);
-    if (!(k > 0.0)) return B;
-    // centre: midpoint of the longest edge if it covers the third vertex, else circumcentre
-    double ctr[3];
-    {
-        const double *p0 = a, *p1 = b, *p2 = c;
-        double e = eab;
-        if (ebc > e) { p0 = b; p1 = c; p2 = a; e = ebc; }
-        if (eca > e) { p0 = c; p1 = a; p2 = b; e = eca; }
-        for (int i = 0; i < 3; i++) ctr[i] = 0.5 * (p0[i] + p1[i]);
-        if (dist3(ctr, p2) > 0.5 * e) {
-            double vw[3], wu[3], uu = eab * eab, vv = eca * eca, ww = Sd * Sd;
-            cross3d(v, cr, vw);
-            cross3d(cr, u, wu);
-            for (int i = 0; i < 3; i++) ctr[i] = a[i] + (uu * vw[i] + vv * wu[i]) / (2.0 * ww);
-        }
-    }
-    float cf[3] = {(float)ctr[0], (float)ctr[1], (float)ctr[2]};
-    double cd[3] = {cf[0], cf[1], cf[2]};
-    if (!std::isfinite(cd[0]) || !std::isfinite(cd[1]) || !std::isfinite(cd[2])) return B;
-    double r0 = std::max(dist3(cd, a), std::max(dist3(cd, b), dist3(cd, c)));
-    // fixed point of delta = f(x(delta)); gamma bounds the fp32 error of one |cross|
+    if (!(k > 0.0)) return kOpenBox;
+    // fixed point of delta = f(x(delta)); gamma bounds the fp32 error of one |cross|,
+    // D the distance from an accepted p to any vertex
     const double gamma = 1.0 / 1048576.0;
     auto f = [&](double delta) {
-        double D = 2.0 * r0 + delta;
+        double D = emax + delta;
         double x = 0.001 * (1.0 + 1e-6) + std::fabs((double)T.S - Sd) + 6.0 * gamma * D * D +
                    gamma * (Sd + 0.001);
         return x / k + std::sqrt(2.0 * Sd * x + x * x) / P;
     };
     double delta = 0.0;
     for (int it = 0; it < 16; it++) delta = f(delta);
-    delta = 1.5 * delta + 1e-6 * r0;
-    if (!std::isfinite(delta) || f(delta) > delta) return B;          // no consistent bound
-    B.c[0] = cd[0]; B.c[1] = cd[1]; B.c[2] = cd[2];
-    B.rho = (r0 + delta) * (1.0 + 1e-5);
+    delta = 1.5 * delta + 1e-6 * emax;
+    if (!std::isfinite(delta) || f(delta) > delta) return kOpenBox;   // no consistent bound
+    Box B;
+    for (int i = 0; i < 3; i++) {
+        B.lo[i] = std::min(a[i], std::min(b[i], c[i])) - delta;
+        B.hi[i] = std::max(a[i], std::max(b[i], c[i])) + delta;
+    }
     return B;
 }
 
-// smallest sphere around two spheres
-void merge(Bound &A, const Bound &Bq)
-{
-    double d = dist3(A.c, Bq.c);
-    if (d + Bq.rho <= A.rho) return;
-    if (d + A.rho <= Bq.rho) { A = Bq; return; }
-    double R = 0.5 * (d + A.rho + Bq.rho);
-    double s = d > 0.0 ? (R - A.rho) / d : 0.0;
-    for (int i = 0; i < 3; i++) A.c[i] += (Bq.c[i] - A.c[i]) * s;
-    A.rho = R;
-}
-
-NodeRec parent_of(const NodeRec *ch, int n)
-{
-    NodeRec out{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
-    Bound acc{{0, 0, 0}, -kInfD};
-    bool have = false;
-    for (int i = 0; i < n; i++) {
-        double r = ch[i].rho;
-        if (r == -kInfD) continue;
-        if (!(r < kInfD)) { out.rho = std::numeric_limits<float>::infinity(); return out; }
-        Bound b{{ch[i].cx, ch[i].cy, ch[i].cz}, r};
-        if (!have) { acc = b; have = true; }
-        else merge(acc, b);
-    }
-    if (!have) return out;
-    out.cx = (float)acc.c[0]; out.cy = (float)acc.c[1]; out.cz = (float)acc.c[2];
-    double cd[3] = {out.cx, out.cy, out.cz}, rho = 0.0;
-    for (int i = 0; i < n; i++) {
-        if (ch[i].rho == -std::numeric_limits<float>::infinity()) continue;
-        double cc[3] = {ch[i].cx, ch[i].cy, ch[i].cz};
-        rho = std::max(rho, dist3(cd, cc) + (double)ch[i].rho);
-    }
-    out.rho = round_up(rho * (1.0 + 1e-6));
-    if (!std::isfinite(cd[0]) || !std::isfinite(cd[1]) || !std::isfinite(cd[2]))
-        out.rho = std::numeric_limits<float>::infinity();
-    return out;
-}
+inline bool box_dead(const Box &b) { return b.lo[0] > b.hi[0]; }
 
 inline uint64_t spread21(uint64_t x)
 {
@@ -220,14 +172,13 @@ void parallel_for(size_t n, F fn)
     for (auto &t : pool) t.join();
 }
 
-// Order the triangles along a Morton curve of their bound centres and stack the
-// implicit 4-ary sphere tree on top.  `tris` arrives in reference traversal order.
+// Order the triangles along a Morton curve of their box centres and stack the
+// implicit 4-ary box tree on top.  `tris` arrives in reference traversal order.
 void build_tree(HostScene &hs)
 {
     const size_t n = hs.tris.size();
-    const float ninf = -std::numeric_limits<float>::infinity();
-    std::vector<Bound> lb(n);
-    parallel_for(n, [&](size_t g) { lb[g] = leaf_bound(hs.tris[g]); });
+    std::vector<Box> lb(n);
+    parallel_for(n, [&](size_t g) { lb[g] = leaf_box(hs.tris[g]); });
 
     double lo[3] = {kInfD, kInfD, kInfD}, hi[3] = {-kInfD, -kInfD, -kInfD}, ext = 0.0;
     for (size_t g = 0; g < n; g++) {
@@ -235,10 +186,10 @@ void build_tree(HostScene &hs)
         const float vv[9] = {T.ax, T.ay, T.az, T.bx, T.by, T.bz, T.cx, T.cy, T.cz};
         for (float x : vv)
             if (std::isfinite(x)) ext = std::max(ext, (double)std::fabs(x));
-        if (std::isfinite(lb[g].rho))
+        if (!box_dead(lb[g]) && std::isfinite(lb[g].lo[0]))
             for (int i = 0; i < 3; i++) {
-                lo[i] = std::min(lo[i], lb[g].c[i]);
-                hi[i] = std::max(hi[i], lb[g].c[i]);
+                lo[i] = std::min(lo[i], 0.5 * (lb[g].lo[i] + lb[g].hi[i]));
+                hi[i] = std::max(hi[i], 0.5 * (lb[g].lo[i] + lb[g].hi[i]));
             }
     }
     for (const SphereRec &S : hs.spheres) {
@@ -251,15 +202,18 @@ void build_tree(HostScene &hs)
         }
     }
     hs.geom_extent = (float)std::min(std::max(ext, 1.0), 1e30);
+    // fp32 slack of the ray side: p = fl(o + t d) lies within 2^-23 (|o| + |p|) of the
+    // exact line, and ray origins are culled only inside [-E, E]^3, E = kCullExtent * extent
+    const double slack = (double)hs.geom_extent * kCullExtent * (1.0 / 524288.0);
 
     std::vector<std::pair<uint64_t, uint32_t>> key(n);
     parallel_for(n, [&](size_t g) {
         uint64_t kx = 0;
-        if (std::isfinite(lb[g].rho)) {
+        if (!box_dead(lb[g]) && std::isfinite(lb[g].lo[0])) {
             uint64_t q[3];
             for (int i = 0; i < 3; i++) {
                 double w = hi[i] - lo[i];
-                double u = w > 0.0 ? (lb[g].c[i] - lo[i]) / w : 0.0;
+                double u = w > 0.0 ? (0.5 * (lb[g].lo[i] + lb[g].hi[i]) - lo[i]) / w : 0.0;
                 q[i] = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
             }
             kx = spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2;
@@ -272,31 +226,50 @@ void build_tree(HostScene &hs)
     std::vector<TriRec> sorted(n_pad);
     std::memset(sorted.data(), 0, n_pad * sizeof(TriRec));     // padding: norma = 0, never hit
     hs.pos_of.assign(n, 0u);
-    std::vector<NodeRec> level(n_pad, NodeRec{0.0f, 0.0f, 0.0f, ninf});
+    std::vector<Box> level(n_pad, kDeadBox);
     parallel_for(n, [&](size_t pos) {
         uint32_t g = key[pos].second;
         sorted[pos] = hs.tris[g];
         hs.pos_of[g] = (uint32_t)pos;
-        const Bound &b = lb[g];
-        NodeRec r{(float)b.c[0], (float)b.c[1], (float)b.c[2], 0.0f};
-        r.rho = b.rho == -kInfD ? ninf : round_up(b.rho);
-        level[pos] = r;
+        Box b = lb[g];
+        if (!box_dead(b))
+            for (int i = 0; i < 3; i++) {
+                b.lo[i] = (double)round_dn(b.lo[i] - slack);
+                b.hi[i] = (double)round_up(b.hi[i] + slack);
+            }
+        level[pos] = b;
     });
     for (size_t pos = n; pos < n_pad; pos++) sorted[pos].orig = -1;
     hs.tris.swap(sorted);
 
-    hs.nodes.clear();
+    hs.groups.clear();
     hs.level_off.clear();
     hs.level_cnt.clear();
     for (;;) {
-        hs.level_off.push_back(hs.nodes.size());
-        hs.level_cnt.push_back((uint32_t)level.size());
-        hs.nodes.insert(hs.nodes.end(), level.begin(), level.end());
-        if (level.size() <= (size_t)kTreeArity) break;
-        size_t np = level.size() / kTreeArity;
-        size_t np_pad = (np + kTreeArity - 1) / kTreeArity * kTreeArity;
-        std::vector<NodeRec> up(np_pad, NodeRec{0.0f, 0.0f, 0.0f, ninf});
-        parallel_for(np, [&](size_t i) { up[i] = parent_of(&level[i * kTreeArity], kTreeArity); });
+        const size_t ng = level.size() / kTreeArity;
+        hs.level_off.push_back(hs.groups.size());
+        hs.level_cnt.push_back((uint32_t)ng);
+        hs.groups.resize(hs.groups.size() + ng);
+        NodeGroup *out = hs.groups.data() + hs.level_off.back();
+        const size_t np_pad = ng <= 1 ? 0 : (ng + kTreeArity - 1) / kTreeArity * kTreeArity;
+        std::vector<Box> up(np_pad, kDeadBox);
+        parallel_for(ng, [&](size_t i) {
+            Box u = kDeadBox;
+            for (int j = 0; j < kTreeArity; j++) {
+                const Box &b = level[i * kTreeArity + j];
+                for (int a = 0; a < 3; a++) {
+                    out[i].lo[a][j] = (float)b.lo[a];        // already float-representable
+                    out[i].hi[a][j] = (float)b.hi[a];
+                }
+                if (box_dead(b)) continue;
+                for (int a = 0; a < 3; a++) {
+                    u.lo[a] = std::min(u.lo[a], b.lo[a]);
+                    u.hi[a] = std::max(u.hi[a], b.hi[a]);
+                }
+            }
+            if (np_pad) up[i] = u;
+        });
+        if (ng <= 1) break;
         level.swap(up);
     }
     hs.top = (int)hs.level_cnt.size() - 1;

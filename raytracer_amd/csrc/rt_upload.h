@@ -13,12 +13,12 @@ struct HostScene {
     std::vector<TriRec> tris;          // tree order, padded to a multiple of kTreeArity
     std::vector<uint32_t> pos_of;      // reference traversal index -> position in `tris`
     std::vector<TriCold> cold;         // reference traversal order
-    // Implicit 4-ary bounding-sphere tree over `tris`: level 0 = one NodeRec per
-    // triangle, level l+1 = one per four nodes of level l; every level padded to a
-    // multiple of 4 with rho = -inf records; the top level has at most 4 nodes.
-    std::vector<NodeRec> nodes;        // all levels back to back
-    std::vector<size_t> level_off;     // first record of level l in `nodes`
-    std::vector<uint32_t> level_cnt;   // padded record count of level l
+    // Implicit 4-ary box tree over `tris`: level 0 = one box per triangle, level l+1 =
+    // one per four boxes of level l, stored four to a NodeGroup; levels are padded
+    // with dead boxes; the top level is a single group.
+    std::vector<NodeGroup> groups;     // all levels back to back
+    std::vector<size_t> level_off;     // first group of level l in `groups`
+    std::vector<uint32_t> level_cnt;   // number of groups of level l
     int top = 0;                       // index of the top level
     float geom_extent = 1.0f;          // max |coordinate| of the geometry
     std::vector<ModelRec> models;

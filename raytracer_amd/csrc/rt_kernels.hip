@@ -13,6 +13,8 @@
 // 64-ray chunks, so a whole sample is enqueued without a host round trip.
 #include "rt_kernels.h"
 
+#include <algorithm>
+
 #include "rt_device.h"
 
 namespace rt {
@@ -80,6 +82,16 @@ __global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t
 // of the wave may still hit below it.  The tests of node_test() only ever discard
 // (ray, triangle) pairs Triangle::hit would reject, so the result is the scan's.
 // CULL = false visits every triangle (validation mode, rt_set_culling(ctx, 0)).
+#ifdef RT_TRAV_STATS
+__device__ unsigned long long g_trav[8];
+__device__ unsigned long long g_hist[32];
+__device__ unsigned short g_cost[2][65536];
+__device__ unsigned int g_launch;
+#define RT_COUNT(k) do { } while (0)
+#else
+#define RT_COUNT(k) do { } while (0)
+#endif
+
 template <int P>
 struct WaveRays {
     RayPair r[P];
@@ -90,11 +102,14 @@ __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, u
                                               WaveRays<P> &w, uint32_t lanebits, int j)
 {
     const TriRec T = tris[node];
+    RT_COUNT(1);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         bool cx = (lanebits >> (j * 2 * P + 2 * p)) & 1u, cy = (lanebits >> (j * 2 * P + 2 * p + 1)) & 1u;
-        if (__ballot(cx | cy))
+        if (__ballot(cx | cy)) {
+            RT_COUNT(2);
             tri_test_pair(T, w.r[p], cx, cy);
+        }
     }
 }
 
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
                                                       float *__restrict__ out_t,
                                                       int32_t *__restrict__ out_id,
                                                       uint32_t *__restrict__ work,
-                                                      uint32_t *__restrict__ work_next)
+                                                      uint32_t *__restrict__ work_next, int dynamic)
 {
     constexpr uint32_t R = 2 * P;
     const uint32_t count = *count_ptr;
@@ -133,17 +148,36 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
     if (blockIdx.x == 0 && threadIdx.x == 0)
         *work_next = 0u;                 // the next launch's dispenser (stream-ordered after us)
     const uint32_t lvloff = tv.level_off[lane & (kMaxLevels - 1)];
-    // Chunks cost anything from a handful of node tests (rays into empty space) to
-    // thousands, so waves draw them from a dispenser instead of striding the queue.
-    // Every wave leaves as soon as it draws a chunk past the end.
+    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+    uint32_t next_chunk = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    // Over a deep tree a chunk costs anything from a handful of node tests (rays into
+    // empty space) to thousands, so waves draw chunks from a dispenser (`dynamic`);
+    // over a shallow one every chunk is cheap, the same-address atomic would be the
+    // bottleneck, and waves stride the queue instead.  Either way every wave leaves as
+    // soon as its next chunk lies past the end.
     for (;;) {
+#ifdef RT_TRAV_STATS
+        long long ta0 = clock64();
+#endif
         uint32_t chunk = 0;
-        if (lane == 0)
-            chunk = atomicAdd(work, 1u);
-        chunk = __builtin_amdgcn_readfirstlane(chunk);
+        if (dynamic) {
+            if (lane == 0)
+                chunk = atomicAdd(work, 1u);
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+        } else {
+            chunk = next_chunk;
+            next_chunk += n_waves;
+        }
+#ifdef RT_TRAV_STATS
+        long long ta1 = clock64();
+        long long t_grp = 0, t_tri = 0; uint32_t n_grp = 0;
+#endif
         if ((unsigned long long)chunk * (64u * R) >= count)
             break;
         const uint32_t base = chunk * 64u * R;
+#ifdef RT_TRAV_STATS
+        long long tc0 = clock64();
+#endif
         WaveRays<P> w;
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -178,7 +212,14 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
                                       (fabsf(d1[0]) <= 2.0f) & (fabsf(d1[1]) <= 2.0f) & (fabsf(d1[2]) <= 2.0f));
         }
 
+        RT_COUNT(3);
+#ifdef RT_TRAV_STATS
+        long long tc1 = clock64();
+#endif
         if (CULL) {
+#ifdef RT_TRAV_STATS
+            uint32_t n_exp = 0;
+#endif
             int l = tv.top;
             uint32_t g = 0;
             uint32_t state = 0;                  // lane l: pending children of level l
@@ -186,7 +227,21 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
             bool expand = true;
             for (;;) {
                 if (expand) {
+#ifdef RT_TRAV_STATS
+                    n_exp++;
+#endif
+#ifdef RT_TRAV_STATS
+                    long long tg0 = clock64();
+#endif
                     const NodeGroup G = tv.groups[lane_get(lvloff, l) + g];
+#ifdef RT_TRAV_STATS
+                    {
+                        float sink = G.lo[0][0] + G.hi[2][3];
+                        asm volatile("" ::"s"(sink));
+                        t_grp += clock64() - tg0;
+                        n_grp++;
+                    }
+#endif
                     uint32_t key[4], lb = 0, n_pass = 0;
 #pragma unroll
                     for (int j = 0; j < kTreeArity; j++) {
@@ -245,11 +300,29 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
                     expand = true;
                 }
             }
+#ifdef RT_TRAV_STATS
+            if (lane == 0) {
+                atomicAdd(&g_trav[0], (unsigned long long)n_exp);
+                if (chunk < 65536) g_cost[g_launch & 1][chunk] = (unsigned short)(n_exp > 65535 ? 65535 : n_exp);
+                atomicAdd(&g_hist[n_exp ? 32 - __builtin_clz(n_exp) : 0], 1ull);
+            }
+#endif
         } else {
             for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
                 test_triangle<P>(tris, node, w, 0xffffffffu, 0);
         }
 
+#ifdef RT_TRAV_STATS
+        long long tc2 = clock64();
+        if (lane == 0) {
+            atomicAdd(&g_trav[1], (unsigned long long)(ta1 - ta0));
+            atomicAdd(&g_trav[2], (unsigned long long)t_grp);
+            atomicAdd(&g_trav[6], (unsigned long long)n_grp);
+            atomicAdd(&g_trav[3], 1ull);
+            atomicAdd(&g_trav[4], (unsigned long long)(tc1 - tc0));
+            atomicAdd(&g_trav[5], (unsigned long long)(tc2 - tc1));
+        }
+#endif
 #pragma unroll
         for (int p = 0; p < P; p++) {
             RayPair &r = w.r[p];
@@ -645,6 +718,30 @@ __global__ void k_median3x3(const float4 *__restrict__ in, float4 *__restrict__ 
     out[(size_t)y * width + x] = temp[count / 2];
 }
 
+#ifdef RT_TRAV_STATS
+extern "C" void rt_debug_costs(unsigned short *out, unsigned launch)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cost), sizeof(unsigned short) * 65536, (launch & 1) * 65536 * sizeof(unsigned short));
+}
+extern "C" void rt_debug_set_launch(unsigned launch)
+{
+    hipDeviceSynchronize();
+    hipMemcpyToSymbol(HIP_SYMBOL(g_launch), &launch, sizeof(launch));
+}
+extern "C" void rt_debug_trav_stats(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav), sizeof(g_trav));
+    hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_hist), sizeof(g_hist));
+    if (reset) {
+        unsigned long long z[32] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_trav), z, sizeof(g_trav));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_hist), z, sizeof(g_hist));
+    }
+}
+#endif
+
 // ------------------------------------------------------------------ launchers
 static inline int grid_for(uint32_t n, int max_blocks)
 {
@@ -669,13 +766,14 @@ void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const 
 {
     // 4 rays per lane when that still leaves every SIMD several waves, else 2
     const bool wide = v.isect_pairs ? v.isect_pairs == 2 : capacity >= (1u << 20);
+    const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
     const uint32_t rays_per_block = kBlock * (wide ? 4u : 2u);
     uint32_t g = (capacity + rays_per_block - 1) / rays_per_block;
     if (g < 1) g = 1;
     if ((int)g > max_blocks) g = (uint32_t)max_blocks;
 #define RT_LAUNCH_INTERSECT(P, CULL)                                                           \
     k_intersect<P, CULL><<<g, kBlock, 0, s>>>(v.tree, v.tris, v.spheres, v.n_tris, v.n_spheres, \
-                                              q, count, out_t, out_id, work, work_next)
+                                              q, count, out_t, out_id, work, work_next, dynamic)
     if (v.cull) {
         if (wide) RT_LAUNCH_INTERSECT(2, true); else RT_LAUNCH_INTERSECT(1, true);
     } else {

@@ -11,9 +11,15 @@ tiles, round-robin; scene replicated) and the step ends with the RCCL gather of 
 partition framebuffers -- total work is fixed, so scaling is "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_intersect, the
-brute-force closest hit): algorithmic bytes per launch / its mean HIP-event duration,
-against the 8 TB/s HBM peak.  `cpu_baseline` is the CPU oracle (a port of the reference's
-per-pixel code) timed on this box's host cores on a bounded crop of the same workload.
+closest hit): algorithmic bytes per launch / its mean HIP-event duration, against the
+8 TB/s HBM peak.  Algorithmic bytes of the culled kernel ("Measurement"):
+32 B per ray (24 B ray in, 8 B (t, id) out) + one pass over the scene records per
+launch (64 B triangle record + 32 B of box tree per triangle).  The figure SURVEY 8(d)
+defined for a plain scan (every ray streams every triangle, one fetch shared by 256
+rays) is reported next to it as `scan_equivalent`: it is what a scan would have had to
+move to produce the same result in the same time.  `cpu_baseline` is the CPU oracle (a
+port of the reference's per-pixel code) timed on this box's host cores on a bounded
+crop of the same workload.
 """
 import argparse
 import ctypes as C
@@ -27,12 +33,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-FP32_PEAK_TFLOPS = 157.3     # vector fp32 peak (counts an FMA as 2 flops)
-TRI_BYTES = 36.0             # 9 floats of positions per triangle
+TRI_BYTES = 36.0             # 9 floats of positions per triangle (scan model)
+TRI_REC_BYTES = 64.0 + 32.0  # culled kernel: TriRec + its share of the box tree (24 B * 4/3)
 SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
 RAY_IO_BYTES = 32.0          # 24 B ray in + 8 B (t, id) out per ray
-FLOPS_PER_TEST = 86.0
 
 
 def parse():
@@ -47,6 +52,20 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=None, metavar=("W", "H"))
     return ap.parse_args()
+
+
+def measured_traffic(cfg_name, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
+    None if there is no profile for this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d[cfg_name][kernel]["bytes_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def cpu_baseline(cfg, spp, crop_wh):
@@ -145,12 +164,15 @@ def main():
         # dominant kernel: closest hit.  Units of one launch = rays; per-unit figure below.
         rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
         launches = max(1, st.intersect_launches)
-        per_ray_bytes = (n_tri * TRI_BYTES + n_sph * SPH_BYTES) / RAYS_PER_FETCH + RAY_IO_BYTES
         k_ms = st.intersect_ms / launches
-        bytes_per_launch = per_ray_bytes * rays_k / launches
+        rays_per_launch = rays_k / launches
+        # culled kernel: ray I/O + the scene records once per launch
+        bytes_per_launch = RAY_IO_BYTES * rays_per_launch + n_tri * TRI_REC_BYTES + n_sph * SPH_BYTES
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # what a scan would have had to move for the same result in the same time
+        scan_per_ray = (n_tri * TRI_BYTES + n_sph * SPH_BYTES) / RAYS_PER_FETCH + RAY_IO_BYTES
+        scan_gbs = scan_per_ray * rays_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         tests = rays_k * (n_tri + n_sph)
-        flops = tests * FLOPS_PER_TEST
         out = {
             "metric": "Mrays/sec (primary+shadow) at 1080p",
             "value": rays_total / dt / 1e6,
@@ -170,19 +192,20 @@ def main():
                        "partition": f"64x64 tiles round-robin over {world} GPU(s)",
                        "rays_per_step": rays_total / a.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(cfg.name, "k_intersect"),
                          "kernel": "k_intersect", "avg_launch_ms": k_ms,
                          "launches_timed": int(launches),
                          "bytes_per_launch": bytes_per_launch,
-                         "note": "brute-force all-pairs scan is VALU-bound by construction "
-                                 "(SURVEY 8(d)); see `valu`"},
-            "valu": {"tests_per_s": tests / (st.intersect_ms * 1e-3) if st.intersect_ms else 0.0,
-                     "algorithmic_tflops": flops / (st.intersect_ms * 1e-3) / 1e12
-                     if st.intersect_ms else 0.0,
-                     "peak_tflops": FP32_PEAK_TFLOPS,
-                     "frac": (flops / (st.intersect_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS)
-                     if st.intersect_ms else 0.0,
-                     "intersect_share_of_step": st.intersect_ms / (st.render_ms or 1.0)},
+                         "rays_per_launch": rays_per_launch,
+                         "intersect_share_of_step": st.intersect_ms / (st.render_ms or 1.0),
+                         "note": "tree traversal is bound by VALU issue and scalar-load "
+                                 "latency, not HBM (DESIGN.md); HBM fraction reported as asked"},
+            "scan_equivalent": {"model": "SURVEY 8(d): every ray streams every primitive, one "
+                                         "fetch per 256 rays",
+                                "gbs": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
+                                "pair_tests_per_s": tests / (st.intersect_ms * 1e-3)
+                                if st.intersect_ms else 0.0},
         }
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (512, 288),

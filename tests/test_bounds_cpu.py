@@ -86,6 +86,30 @@ def test_accepted_pairs_pass_the_box_test(kind):
     assert n_accept > (200 if kind != "tiny" else 0)
 
 
+def test_box_test_has_teeth():
+    """The same check fails once the boxes are shrunk by 3 %: the bound is not vacuous."""
+    rng = np.random.default_rng(9)
+    fails = 0
+    for _ in range(20):
+        tri = random_triangle(rng, "normal")
+        b = SceneBuilder()
+        b.add_triangle(tri, [(0, 0, 1)] * 3, identity(), (0.7, 0.7, 0.7))
+        scene = b.build()
+        bounds, pos, ext = abi.host_bounds(scene)
+        n = 3000
+        w = rng.dirichlet([1, 1, 0.02], n)
+        tgt = (w[:, :, None] * tri[None].astype(np.float64)).sum(1)
+        org = (tgt + rng.normal(size=(n, 3)) * 40).astype(np.float32)
+        d = (tgt - org.astype(np.float64)).astype(np.float32)
+        t, pid, hit = orc.scene_hit(scene, org, d)
+        acc = pid == 0
+        box = bounds[0].copy()
+        c, h = (box[:3] + box[3:]) / 2, (box[3:] - box[:3]) / 2 * 0.97
+        box[:3], box[3:] = c - h, c + h
+        fails += int((~node_pass(box, org[acc], normalize32(d[acc]), ext)).sum())
+    assert fails > 100
+
+
 def test_invisible_triangles_are_marked():
     """H1: 2*area below 0.01 can never pass Model.cu:99 -> dead box (lo > hi)."""
     b = SceneBuilder()

@@ -154,8 +154,6 @@ int alloc_shadow(rt_context *c)
     if ((rc = dalloc(c, c->part_allocs, c->v.sh_thr, need))) return rc;
     for (int k = 0; k < 3; k++)
         if ((rc = dalloc(c, c->part_allocs, c->v.sh_contrib[k], need))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, c->v.sh_hit_t, need))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, c->v.sh_hit_id, need))) return rc;
     c->shadow_cap = need;
     return RT_OK;
 }
@@ -189,8 +187,6 @@ int setup_partition(rt_context *c)
         if ((rc = alloc_queue(c, c->part_allocs, v.rays[k], b, true))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.hit_t, b))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.hit_id, b))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, v.sh_mask, b))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, v.sh_base, b / 64 + 2))) return rc;
     if ((rc = alloc_shadow(c))) return rc;
     return RT_OK;
 }
@@ -205,7 +201,6 @@ int do_reset(rt_context *c)
         RT_HIP(c, hipMemsetAsync(v.first_t, 0, n * sizeof(float), c->stream));
         launch_fill_i32(c->stream, v.first_id, n, -1);
     }
-    RT_HIP(c, hipMemsetAsync(v.sh_base, 0, (c->batch / 64 + 2) * sizeof(uint32_t), c->stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     c->cnt = 0;
     return RT_OK;
@@ -236,8 +231,10 @@ void resolve_events(rt_context *c)
 }
 
 // One closest-hit launch, optionally bracketed by HIP events on the launch stream.
+// sh_thr != nullptr: shadow form over n_slabs light slabs of `stride` slots.
 void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, uint32_t cap,
-                     float *out_t, int32_t *out_id)
+                     float *out_t, int32_t *out_id, float *sh_thr = nullptr, uint32_t stride = 0,
+                     uint32_t n_slabs = 1)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -245,8 +242,9 @@ void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, ui
         e1 = next_event(c);
     }
     if (e0) (void)hipEventRecord(e0, c->stream);
-    launch_intersect(c->stream, c->v, q, count, cap, out_t, out_id, c->max_blocks,
-                     &c->v.ctl->work[c->isect_seq & 1u], &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
+    launch_intersect(c->stream, c->v, q, count, cap, out_t, out_id, sh_thr, stride, n_slabs,
+                     c->max_blocks, &c->v.ctl->work[c->isect_seq & 1u],
+                     &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
     c->isect_seq++;
     if (e1) (void)hipEventRecord(e1, c->stream);
     c->launches++;
@@ -450,13 +448,12 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
                 for (int pass = 0; pass < n_pass; pass++) {
                     const int l0 = pass * kLightsPerPass;
                     const int nl = std::max(0, std::min(kLightsPerPass, L - l0));
-                    launch_shade(s, v, n, cur, bounce, l0, nl, L, c->max_blocks);
-                    if (nl > 0)
-                        timed_intersect(c, v.shadow, &v.ctl->n_shadow, (uint32_t)std::min<size_t>((size_t)n * nl, 0xffffffffu),
-                                        v.sh_hit_t, v.sh_hit_id);
+                    launch_shade(s, v, n, cur, bounce, l0, nl, L, c->batch, c->max_blocks);
+                    if (nl > 0)         // shadow rays of this pass: nl light slabs of `batch` slots
+                        timed_intersect(c, v.shadow, &v.ctl->n_cur, n, nullptr, nullptr, v.sh_thr,
+                                        c->batch, (uint32_t)nl);
                     launch_finish(s, v, n, cur, bounce, max_depth, l0, nl, pass == n_pass - 1,
-                                  c->max_blocks);
-                    launch_ctl_after_shadow(s, v.ctl);
+                                  c->batch, c->max_blocks);
                 }
                 launch_ctl_next_bounce(s, v.ctl);
                 cur ^= 1;
@@ -575,7 +572,7 @@ extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float 
         if (e == hipSuccess) e = hipMemcpyAsync(d_count, &un, 4, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
             launch_prepare_rays(s, q, d_org, d_dir, un);
-            launch_intersect(s, c->v, q, d_count, un, d_t, d_id, c->max_blocks,
+            launch_intersect(s, c->v, q, d_count, un, d_t, d_id, nullptr, 0, 1, c->max_blocks,
                              &c->v.ctl->work[c->isect_seq & 1u],
                              &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
             c->isect_seq++;

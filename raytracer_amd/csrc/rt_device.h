@@ -140,6 +140,7 @@ struct RayPair {
     f2 ix, iy, iz;    // 1 / d per axis (|d| clamped away from 0) for the box tests only
     f2 best;          // running closest t per ray (IntersectRecord::t)
     f2 bestp;         // best * (1 + 2^-19): conservative side of every pre-test
+    f2 stop;          // shadow rays: a hit with t below this ends the ray (-1: never)
     int idx, idy;     // reference traversal index of the closest primitive, -1 = none
     bool wildx, wildy;   // origin outside the culling extent (or not finite): never culled
 };

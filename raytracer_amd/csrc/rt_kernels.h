@@ -12,8 +12,7 @@ namespace rt {
 struct Ctl {
     uint32_t n_cur;        // active paths of the current bounce
     uint32_t n_next;       // survivors pushed for the next bounce
-    uint32_t n_shadow;     // shadow rays pushed by the current light pass
-    uint32_t pad;
+    uint32_t pad[2];
     // Chunk dispensers of the closest-hit kernel (one per launch parity): waves draw
     // 64*R-ray chunks with atomicAdd; launch k uses work[k & 1] and zeroes the other.
     uint32_t work[2];
@@ -67,28 +66,24 @@ struct DevView {
     RayQueue rays[2];
     float *hit_t;
     int32_t *hit_id;
-    unsigned long long *sh_mask;
-    uint32_t *sh_base;
     // shadow-ray queue
     RayQueue shadow;
-    float *sh_thr;
+    float *sh_thr;                  // in: |o - l| - 0.01 (or -1: empty slot); out: 1 blocked / 0 visible
     float *sh_contrib[3];
-    float *sh_hit_t;
-    int32_t *sh_hit_id;
     Ctl *ctl;
 };
 
 void launch_ctl_begin(hipStream_t s, Ctl *ctl, uint32_t n);
-void launch_ctl_after_shadow(hipStream_t s, Ctl *ctl);
 void launch_ctl_next_bounce(hipStream_t s, Ctl *ctl);
 void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n);
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
-                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks,
-                      uint32_t *work, uint32_t *work_next);
+                      uint32_t capacity, float *out_t, int32_t *out_id, float *sh_thr,
+                      uint32_t stride, uint32_t n_slabs, int max_blocks, uint32_t *work,
+                      uint32_t *work_next);
 void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
-                  int nl, int n_lights_total, int max_blocks);
+                  int nl, int n_lights_total, uint32_t stride, int max_blocks);
 void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,
-                   int max_depth, int l0, int nl, int last_pass, int max_blocks);
+                   int max_depth, int l0, int nl, int last_pass, uint32_t stride, int max_blocks);
 void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,
                           const int32_t *first_id, const float *first_t, float4 *rgba,
                           int32_t *prim, float *t);

@@ -30,12 +30,6 @@ __global__ void k_ctl_begin(Ctl *ctl, uint32_t n)
 {
     ctl->n_cur = n;
     ctl->n_next = 0;
-    ctl->n_shadow = 0;
-}
-__global__ void k_ctl_after_shadow(Ctl *ctl)
-{
-    ctl->shadow_total += ctl->n_shadow;
-    ctl->n_shadow = 0;
 }
 __global__ void k_ctl_next_bounce(Ctl *ctl)
 {
@@ -82,15 +76,6 @@ __global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t
 // of the wave may still hit below it.  The tests of node_test() only ever discard
 // (ray, triangle) pairs Triangle::hit would reject, so the result is the scan's.
 // CULL = false visits every triangle (validation mode, rt_set_culling(ctx, 0)).
-#ifdef RT_TRAV_STATS
-__device__ unsigned long long g_trav[8];
-__device__ unsigned long long g_hist[32];
-__device__ unsigned short g_cost[2][65536];
-__device__ unsigned int g_launch;
-#define RT_COUNT(k) do { } while (0)
-#else
-#define RT_COUNT(k) do { } while (0)
-#endif
 
 template <int P>
 struct WaveRays {
@@ -102,13 +87,16 @@ __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, u
                                               WaveRays<P> &w, uint32_t lanebits, int j)
 {
     const TriRec T = tris[node];
-    RT_COUNT(1);
 #pragma unroll
     for (int p = 0; p < P; p++) {
         bool cx = (lanebits >> (j * 2 * P + 2 * p)) & 1u, cy = (lanebits >> (j * 2 * P + 2 * p + 1)) & 1u;
         if (__ballot(cx | cy)) {
-            RT_COUNT(2);
             tri_test_pair(T, w.r[p], cx, cy);
+            // shadow rays (occlusion form): a hit safely below the threshold ends the ray --
+            // nothing can pass its node tests any more
+            RayPair &r = w.r[p];
+            if (r.best.x < r.stop.x) { r.bestp.x = -1.0f; r.wildx = false; }
+            if (r.best.y < r.stop.y) { r.bestp.y = -1.0f; r.wildy = false; }
         }
     }
 }
@@ -132,18 +120,32 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
     a = lo; b = hi;
 }
 
-template <int P, bool CULL>
+// SHADOW = true is the shadow-ray form of the same traversal (Scene.cu:224-227): the queue
+// holds n_slabs slabs of `stride` slots, slot j * stride + i = the ray from path i towards
+// light j (light-major, so a chunk's rays head for ONE light from neighbouring pixels);
+// sh_thr[slot] is the threshold |o - l| - 0.01 of Scene.cu:227, or < 0 for an empty slot, and
+// receives the verdict: 1 = blocked, 0 = visible.  Without quadrics in the scene the closest
+// hit itself is not needed, only `|hit - o| < thr`: hits beyond thr + m cannot matter and the
+// ray stops at the first hit below thr - m, m covering the difference between t and the
+// reference's |fl(o + t d) - o|; inside the band the true closest hit decides, exactly as
+// the reference computes it.
+template <int P, bool CULL, bool SHADOW>
 __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec *__restrict__ tris,
                                                       const SphereRec *__restrict__ spheres,
                                                       int n_tris, int n_spheres, RayQueue q,
                                                       const uint32_t *__restrict__ count_ptr,
                                                       float *__restrict__ out_t,
                                                       int32_t *__restrict__ out_id,
+                                                      float *__restrict__ sh_thr, uint32_t stride,
+                                                      uint32_t n_slabs,
                                                       uint32_t *__restrict__ work,
                                                       uint32_t *__restrict__ work_next, int dynamic)
 {
     constexpr uint32_t R = 2 * P;
     const uint32_t count = *count_ptr;
+    const uint32_t chunks_per_slab = (count + 64u * R - 1u) / (64u * R);
+    const uint32_t n_chunks = chunks_per_slab * (SHADOW ? n_slabs : 1u);
+    const bool occlusion = SHADOW && n_spheres == 0;
     const uint32_t lane = threadIdx.x & 63u;
     if (blockIdx.x == 0 && threadIdx.x == 0)
         *work_next = 0u;                 // the next launch's dispenser (stream-ordered after us)
@@ -156,9 +158,6 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
     // bottleneck, and waves stride the queue instead.  Either way every wave leaves as
     // soon as its next chunk lies past the end.
     for (;;) {
-#ifdef RT_TRAV_STATS
-        long long ta0 = clock64();
-#endif
         uint32_t chunk = 0;
         if (dynamic) {
             if (lane == 0)
@@ -168,34 +167,51 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
             chunk = next_chunk;
             next_chunk += n_waves;
         }
-#ifdef RT_TRAV_STATS
-        long long ta1 = clock64();
-        long long t_grp = 0, t_tri = 0; uint32_t n_grp = 0;
-#endif
-        if ((unsigned long long)chunk * (64u * R) >= count)
+        if (chunk >= n_chunks)
             break;
-        const uint32_t base = chunk * 64u * R;
-#ifdef RT_TRAV_STATS
-        long long tc0 = clock64();
-#endif
+        const uint32_t slab = SHADOW ? chunk / chunks_per_slab : 0u;
+        const uint32_t base = (chunk - slab * chunks_per_slab) * 64u * R;   // path position
+        const uint32_t qbase = slab * stride + base;                       // queue position
         WaveRays<P> w;
+        float thr[R];
+        bool live[R];
+        bool any_live = false;
+#pragma unroll
+        for (int k = 0; k < (int)R; k++) {
+            live[k] = base + k * 64u + lane < count;
+            thr[k] = 0.0f;
+            if (SHADOW) {
+                thr[k] = live[k] ? sh_thr[qbase + k * 64u + lane] : -1.0f;
+                live[k] = thr[k] >= 0.0f;
+            }
+            any_live |= live[k];
+        }
+        if (SHADOW && !__ballot(any_live))
+            continue;                            // a chunk of empty slots (e.g. sky pixels)
 #pragma unroll
         for (int p = 0; p < P; p++) {
             RayPair &r = w.r[p];
-            uint32_t i0 = base + (2 * p) * 64u + lane, i1 = i0 + 64u;
-            // rays past the end of the queue: parked far away with an empty t window
+            uint32_t i0 = qbase + (2 * p) * 64u + lane, i1 = i0 + 64u;
+            // dead lanes: parked far away with an empty t window
             float o0[3] = {0.0f, 1e18f, 0.0f}, d0[3] = {1.0f, 0.0f, 0.0f};
             float o1[3] = {0.0f, 1e18f, 0.0f}, d1[3] = {1.0f, 0.0f, 0.0f};
             float b0 = 0.0f, b1 = 0.0f;
-            if (i0 < count) {
+            if (live[2 * p]) {
                 o0[0] = q.ox[i0]; o0[1] = q.oy[i0]; o0[2] = q.oz[i0];
                 d0[0] = q.dx[i0]; d0[1] = q.dy[i0]; d0[2] = q.dz[i0];
                 b0 = kInf;                                   // IntersectRecord(): t = INF
             }
-            if (i1 < count) {
+            if (live[2 * p + 1]) {
                 o1[0] = q.ox[i1]; o1[1] = q.oy[i1]; o1[2] = q.oz[i1];
                 d1[0] = q.dx[i1]; d1[1] = q.dy[i1]; d1[2] = q.dz[i1];
                 b1 = kInf;
+            }
+            r.stop = f2{-1.0f, -1.0f};
+            if (occlusion) {
+                float m0 = 1e-4f * (fabsf(thr[2 * p]) + fabsf(o0[0]) + fabsf(o0[1]) + fabsf(o0[2])) + 1e-6f;
+                float m1 = 1e-4f * (fabsf(thr[2 * p + 1]) + fabsf(o1[0]) + fabsf(o1[1]) + fabsf(o1[2])) + 1e-6f;
+                if (live[2 * p]) { b0 = fminf(kInf, thr[2 * p] + m0); r.stop.x = thr[2 * p] - m0; }
+                if (live[2 * p + 1]) { b1 = fminf(kInf, thr[2 * p + 1] + m1); r.stop.y = thr[2 * p + 1] - m1; }
             }
             r.ox = f2{o0[0], o1[0]}; r.oy = f2{o0[1], o1[1]}; r.oz = f2{o0[2], o1[2]};
             r.dx = f2{d0[0], d1[0]}; r.dy = f2{d0[1], d1[1]}; r.dz = f2{d0[2], d1[2]};
@@ -206,20 +222,13 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
             r.bestp = r.best * kBestInfl;
             r.idx = -1; r.idy = -1;
             const float E = tv.extent;
-            r.wildx = (i0 < count) & !((fabsf(o0[0]) <= E) & (fabsf(o0[1]) <= E) & (fabsf(o0[2]) <= E) &
+            r.wildx = live[2 * p] & !((fabsf(o0[0]) <= E) & (fabsf(o0[1]) <= E) & (fabsf(o0[2]) <= E) &
                                       (fabsf(d0[0]) <= 2.0f) & (fabsf(d0[1]) <= 2.0f) & (fabsf(d0[2]) <= 2.0f));
-            r.wildy = (i1 < count) & !((fabsf(o1[0]) <= E) & (fabsf(o1[1]) <= E) & (fabsf(o1[2]) <= E) &
-                                      (fabsf(d1[0]) <= 2.0f) & (fabsf(d1[1]) <= 2.0f) & (fabsf(d1[2]) <= 2.0f));
+            r.wildy = live[2 * p + 1] & !((fabsf(o1[0]) <= E) & (fabsf(o1[1]) <= E) & (fabsf(o1[2]) <= E) &
+                                          (fabsf(d1[0]) <= 2.0f) & (fabsf(d1[1]) <= 2.0f) & (fabsf(d1[2]) <= 2.0f));
         }
 
-        RT_COUNT(3);
-#ifdef RT_TRAV_STATS
-        long long tc1 = clock64();
-#endif
         if (CULL) {
-#ifdef RT_TRAV_STATS
-            uint32_t n_exp = 0;
-#endif
             int l = tv.top;
             uint32_t g = 0;
             uint32_t state = 0;                  // lane l: pending children of level l
@@ -227,21 +236,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
             bool expand = true;
             for (;;) {
                 if (expand) {
-#ifdef RT_TRAV_STATS
-                    n_exp++;
-#endif
-#ifdef RT_TRAV_STATS
-                    long long tg0 = clock64();
-#endif
                     const NodeGroup G = tv.groups[lane_get(lvloff, l) + g];
-#ifdef RT_TRAV_STATS
-                    {
-                        float sink = G.lo[0][0] + G.hi[2][3];
-                        asm volatile("" ::"s"(sink));
-                        t_grp += clock64() - tg0;
-                        n_grp++;
-                    }
-#endif
                     uint32_t key[4], lb = 0, n_pass = 0;
 #pragma unroll
                     for (int j = 0; j < kTreeArity; j++) {
@@ -300,35 +295,17 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
                     expand = true;
                 }
             }
-#ifdef RT_TRAV_STATS
-            if (lane == 0) {
-                atomicAdd(&g_trav[0], (unsigned long long)n_exp);
-                if (chunk < 65536) g_cost[g_launch & 1][chunk] = (unsigned short)(n_exp > 65535 ? 65535 : n_exp);
-                atomicAdd(&g_hist[n_exp ? 32 - __builtin_clz(n_exp) : 0], 1ull);
-            }
-#endif
         } else {
             for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
                 test_triangle<P>(tris, node, w, 0xffffffffu, 0);
         }
 
-#ifdef RT_TRAV_STATS
-        long long tc2 = clock64();
-        if (lane == 0) {
-            atomicAdd(&g_trav[1], (unsigned long long)(ta1 - ta0));
-            atomicAdd(&g_trav[2], (unsigned long long)t_grp);
-            atomicAdd(&g_trav[6], (unsigned long long)n_grp);
-            atomicAdd(&g_trav[3], 1ull);
-            atomicAdd(&g_trav[4], (unsigned long long)(tc1 - tc0));
-            atomicAdd(&g_trav[5], (unsigned long long)(tc2 - tc1));
-        }
-#endif
 #pragma unroll
         for (int p = 0; p < P; p++) {
             RayPair &r = w.r[p];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                uint32_t i = base + (2 * p + h) * 64u + lane;
+                uint32_t i = qbase + (2 * p + h) * 64u + lane;
                 v3 o = mk3(h ? r.ox.y : r.ox.x, h ? r.oy.y : r.oy.x, h ? r.oz.y : r.oz.x);
                 v3 d = mk3(h ? r.dx.y : r.dx.x, h ? r.dy.y : r.dy.x, h ? r.dz.y : r.dz.x);
                 float best = h ? r.best.y : r.best.x;
@@ -340,7 +317,20 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
                         id = n_tris + s;
                     }
                 }
-                if (i < count) {
+                if (!live[2 * p + h])
+                    continue;
+                if (SHADOW) {
+                    // Scene.cu:225-227: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
+                    // (H3: `lightidx == idx` restated as never true for point lights)
+                    bool blocked = false;
+                    if (scene_ishit(best) && id >= 0) {
+                        Ray sr; sr.o = o; sr.d = d;
+                        v3 hp = id < n_tris ? ray_pos(sr, best)
+                                            : hit_pos_sphere(spheres[id - n_tris], sr, best);
+                        blocked = length(sub(hp, o)) < thr[2 * p + h];
+                    }
+                    sh_thr[i] = blocked ? 1.0f : 0.0f;
+                } else {
                     out_t[i] = best;
                     out_id[i] = id;
                 }
@@ -396,21 +386,19 @@ __device__ __forceinline__ LightSample sample_point_light(const Hit &h, const Mo
 // ------------------------------------------------------------------ shade: spawn shadow rays
 // For every active path of the current bounce: draw the bounce's uniform4
 // (PathTracer.cu:27), classify hit / miss (PathTracer.cu:64), and for lights
-// [l0, l0 + nl) push one shadow ray per (hit, light) whose BRDF term is not black
-// (Scene.cu:224), compacted with wave ballots: a block reserves one contiguous
-// range of the shadow queue per pass, light-major inside each wave so that a wave
-// of the shadow pass holds neighbouring pixels towards the same light.
+// [l0, l0 + nl) write one shadow ray per (hit, light) whose BRDF term is not black
+// (Scene.cu:224) into slot j * stride + i of the light-major shadow queue (i = the
+// path's queue position): a slab per light, so a chunk of the shadow pass holds
+// neighbouring pixels towards ONE light.  Slots that cast nothing get thr = -1; the
+// shadow pass finds them with one load and skips whole chunks of them by ballot.
 __global__ __launch_bounds__(kBlock) void k_shade(DevView v, int cur, int bounce, int l0, int nl,
-                                                  int n_lights_total)
+                                                  int n_lights_total, uint32_t stride)
 {
-    __shared__ uint32_t s_tot[kWavesPerBlock];
-    __shared__ uint32_t s_base;
     const uint32_t count = v.ctl->n_cur;
-    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     const RayQueue q = v.rays[cur];
-    for (uint32_t group = blockIdx.x; group * kBlock < count; group += gridDim.x) {
-        uint32_t chunk = group * kWavesPerBlock + wib;
-        uint32_t i = chunk * 64u + lane;
+    uint32_t n_cast = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i - threadIdx.x < count;
+         i += gridDim.x * kBlock) {
         bool valid = i < count;
         uint32_t p = 0;
         Ray r;
@@ -442,66 +430,40 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevView v, int cur, int bounce
         if (ishit)
             fill_hit(v, r, id, h);
         const ModelRec *M = ishit ? &v.models[h.model] : &v.models[0];
-
-        // pass 1: which lights cast a ray from this hit
-        uint64_t mask = 0;
-        uint32_t wave_total = 0;
         for (int j = 0; j < nl; j++) {
+            const uint32_t e = (uint32_t)j * stride + i;
             bool cast = false;
-            if (ishit)
-                cast = sample_point_light(h, *M, r.d, v.lights[l0 + j]).cast;
-            uint64_t b = __ballot(cast);
-            if (cast)
-                mask |= (1ull << j);
-            wave_total += (uint32_t)__popcll(b);
-        }
-        // block-level reservation in the shadow queue
-        if (lane == 0)
-            s_tot[wib] = wave_total;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < kWavesPerBlock; w++)
-                tot += s_tot[w];
-            s_base = tot ? atomicAdd(&v.ctl->n_shadow, tot) : 0u;
-        }
-        __syncthreads();
-        uint32_t base = s_base;
-        for (uint32_t w = 0; w < wib; w++)
-            base += s_tot[w];
-        __syncthreads();
-        if (valid) {
-            v.sh_mask[i] = mask;
-            if (lane == 0)
-                v.sh_base[chunk] = base;
-        }
-        // pass 2: write the entries, light-major within the wave
-        uint32_t off = base;
-        for (int j = 0; j < nl; j++) {
-            bool cast = (mask >> j) & 1ull;
-            uint64_t b = __ballot(cast);
-            if (cast) {
+            if (ishit) {
                 LightSample s = sample_point_light(h, *M, r.d, v.lights[l0 + j]);
-                uint32_t e = off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-                RayQueue sq = v.shadow;
-                sq.ox[e] = s.sr.o.x; sq.oy[e] = s.sr.o.y; sq.oz[e] = s.sr.o.z;
-                sq.dx[e] = s.sr.d.x; sq.dy[e] = s.sr.d.y; sq.dz[e] = s.sr.d.z;
-                v.sh_thr[e] = s.thr;
-                v.sh_contrib[0][e] = s.contrib.x;
-                v.sh_contrib[1][e] = s.contrib.y;
-                v.sh_contrib[2][e] = s.contrib.z;
+                cast = s.cast;
+                if (cast) {
+                    RayQueue sq = v.shadow;
+                    sq.ox[e] = s.sr.o.x; sq.oy[e] = s.sr.o.y; sq.oz[e] = s.sr.o.z;
+                    sq.dx[e] = s.sr.d.x; sq.dy[e] = s.sr.d.y; sq.dz[e] = s.sr.d.z;
+                    // Scene.cu:227 rhs; a negative one (hit within 0.01 of the light) can
+                    // never be undercut, and 0 keeps the slot apart from the empty ones
+                    v.sh_thr[e] = fmaxf(s.thr, 0.0f);
+                    v.sh_contrib[0][e] = s.contrib.x;
+                    v.sh_contrib[1][e] = s.contrib.y;
+                    v.sh_contrib[2][e] = s.contrib.z;
+                }
             }
-            off += (uint32_t)__popcll(b);
+            if (valid && !cast)
+                v.sh_thr[e] = -1.0f;
+            n_cast += (uint32_t)__popcll(__ballot(cast));
         }
     }
+    // shadow rays actually cast (statistics only): one fire-and-forget add per wave
+    if ((threadIdx.x & 63u) == 0 && n_cast)
+        atomicAdd(&v.ctl->shadow_total, (unsigned long long)n_cast);
 }
 
 // ------------------------------------------------------------------ finish the bounce
-// Same chunk <-> lane mapping as k_shade, so the ballots reproduce every entry's
-// slot.  Adds the unblocked contributions in light order (Scene.cu:120, 227-249),
-// then, after the last light pass, PathTracer.cu:73-88.
+// Adds the unblocked contributions in light order (Scene.cu:120, 227-249: the shadow
+// pass left 0 = visible / 1 = blocked / -1 = not cast in each slot), then, after the
+// last light pass, PathTracer.cu:73-88.
 __global__ __launch_bounds__(kBlock) void k_finish(DevView v, int cur, int bounce, int max_depth,
-                                                   int l0, int nl, int last_pass)
+                                                   int l0, int nl, int last_pass, uint32_t stride)
 {
     __shared__ uint32_t s_tot[kWavesPerBlock];
     __shared__ uint32_t s_base;
@@ -510,54 +472,31 @@ __global__ __launch_bounds__(kBlock) void k_finish(DevView v, int cur, int bounc
     const RayQueue q = v.rays[cur];
     const RayQueue qn = v.rays[cur ^ 1];
     for (uint32_t group = blockIdx.x; group * kBlock < count; group += gridDim.x) {
-        uint32_t chunk = group * kWavesPerBlock + wib;
-        uint32_t i = chunk * 64u + lane;
+        uint32_t i = group * kBlock + threadIdx.x;
         bool valid = i < count;
         uint32_t p = 0;
         Ray r;
         r.o = mk3(0, 0, 0); r.d = mk3(0, 0, 0);
         float t = kInf;
         int32_t id = -1;
-        uint64_t mask = 0;
         if (valid) {
             p = q.path[i];
             r.o = mk3(q.ox[i], q.oy[i], q.oz[i]);
             r.d = mk3(q.dx[i], q.dy[i], q.dz[i]);
             t = v.hit_t[i];
             id = v.hit_id[i];
-            mask = v.sh_mask[i];
         }
         bool ishit = valid && scene_ishit(t) && id >= 0;
-        uint32_t off = v.sh_base[valid ? chunk : 0];
 
         // res += evaluateDirectLight(...) per light, in order (Scene.cu:120)
         v3 le = mk3(0, 0, 0);
-        if (ishit)
+        if (ishit) {
             le = mk3(v.le[0][p], v.le[1][p], v.le[2][p]);
-        for (int j = 0; j < nl; j++) {
-            bool cast = (mask >> j) & 1ull;
-            uint64_t b = __ballot(cast);
-            v3 c = mk3(0.0f, 0.0f, 0.0f);
-            if (cast) {
-                uint32_t e = off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-                float st = v.sh_hit_t[e];
-                int32_t sid = v.sh_hit_id[e];
-                bool blocked = false;
-                if (scene_ishit(st) && sid >= 0) {                       // Scene.cu:225
-                    Ray sr;
-                    sr.o = mk3(v.shadow.ox[e], v.shadow.oy[e], v.shadow.oz[e]);
-                    sr.d = mk3(v.shadow.dx[e], v.shadow.dy[e], v.shadow.dz[e]);
-                    v3 hp = sid < v.n_tris ? ray_pos(sr, st)
-                                           : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, st);
-                    // H3: `lightidx == idx` restated as never true for point lights
-                    blocked = length(sub(hp, sr.o)) < v.sh_thr[e];       // Scene.cu:227
-                }
-                if (!blocked)                                            // Scene.cu:236
-                    c = mk3(v.sh_contrib[0][e], v.sh_contrib[1][e], v.sh_contrib[2][e]);
+            for (int j = 0; j < nl; j++) {
+                const uint32_t e = (uint32_t)j * stride + i;
+                if (v.sh_thr[e] == 0.0f)                                 // cast and not blocked (Scene.cu:236)
+                    le = add(le, mk3(v.sh_contrib[0][e], v.sh_contrib[1][e], v.sh_contrib[2][e]));
             }
-            if (ishit)
-                le = add(le, c);
-            off += (uint32_t)__popcll(b);
         }
 
         bool survive = false;
@@ -603,8 +542,8 @@ __global__ __launch_bounds__(kBlock) void k_finish(DevView v, int cur, int bounc
                 v.res[0][p] = res.x; v.res[1][p] = res.y; v.res[2][p] = res.z;
             }
         }
-        if (!last_pass)
-            continue;                         // uniform: no barriers below are skipped unevenly
+        if (!last_pass || bounce >= max_depth)
+            continue;                         // uniform: nothing survives the last bounce
         // compaction of the surviving paths into the next bounce's queue
         uint64_t b = __ballot(survive);
         if (lane == 0)
@@ -718,29 +657,6 @@ __global__ void k_median3x3(const float4 *__restrict__ in, float4 *__restrict__ 
     out[(size_t)y * width + x] = temp[count / 2];
 }
 
-#ifdef RT_TRAV_STATS
-extern "C" void rt_debug_costs(unsigned short *out, unsigned launch)
-{
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cost), sizeof(unsigned short) * 65536, (launch & 1) * 65536 * sizeof(unsigned short));
-}
-extern "C" void rt_debug_set_launch(unsigned launch)
-{
-    hipDeviceSynchronize();
-    hipMemcpyToSymbol(HIP_SYMBOL(g_launch), &launch, sizeof(launch));
-}
-extern "C" void rt_debug_trav_stats(unsigned long long *out, int reset)
-{
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav), sizeof(g_trav));
-    hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_hist), sizeof(g_hist));
-    if (reset) {
-        unsigned long long z[32] = {};
-        hipMemcpyToSymbol(HIP_SYMBOL(g_trav), z, sizeof(g_trav));
-        hipMemcpyToSymbol(HIP_SYMBOL(g_hist), z, sizeof(g_hist));
-    }
-}
-#endif
 
 // ------------------------------------------------------------------ launchers
 static inline int grid_for(uint32_t n, int max_blocks)
@@ -752,7 +668,6 @@ static inline int grid_for(uint32_t n, int max_blocks)
 }
 
 void launch_ctl_begin(hipStream_t s, Ctl *ctl, uint32_t n) { k_ctl_begin<<<1, 1, 0, s>>>(ctl, n); }
-void launch_ctl_after_shadow(hipStream_t s, Ctl *ctl) { k_ctl_after_shadow<<<1, 1, 0, s>>>(ctl); }
 void launch_ctl_next_bounce(hipStream_t s, Ctl *ctl) { k_ctl_next_bounce<<<1, 1, 0, s>>>(ctl); }
 
 void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n)
@@ -760,40 +675,47 @@ void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n)
     k_gen<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(v, p0, n);
 }
 
+// One launch of the closest-hit kernel over `capacity` queue slots at most.  Shadow form:
+// sh_thr != nullptr, the queue is n_slabs slabs of `stride` slots (see k_intersect).
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
-                      uint32_t capacity, float *out_t, int32_t *out_id, int max_blocks,
-                      uint32_t *work, uint32_t *work_next)
+                      uint32_t capacity, float *out_t, int32_t *out_id, float *sh_thr,
+                      uint32_t stride, uint32_t n_slabs, int max_blocks, uint32_t *work,
+                      uint32_t *work_next)
 {
     // 4 rays per lane when that still leaves every SIMD several waves, else 2
     const bool wide = v.isect_pairs ? v.isect_pairs == 2 : capacity >= (1u << 20);
     const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
     const uint32_t rays_per_block = kBlock * (wide ? 4u : 2u);
-    uint32_t g = (capacity + rays_per_block - 1) / rays_per_block;
-    if (g < 1) g = 1;
-    if ((int)g > max_blocks) g = (uint32_t)max_blocks;
-#define RT_LAUNCH_INTERSECT(P, CULL)                                                           \
-    k_intersect<P, CULL><<<g, kBlock, 0, s>>>(v.tree, v.tris, v.spheres, v.n_tris, v.n_spheres, \
-                                              q, count, out_t, out_id, work, work_next, dynamic)
-    if (v.cull) {
-        if (wide) RT_LAUNCH_INTERSECT(2, true); else RT_LAUNCH_INTERSECT(1, true);
+    unsigned long long gl = ((unsigned long long)capacity + rays_per_block - 1) / rays_per_block;
+    if (sh_thr) gl *= n_slabs;
+    uint32_t g = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(gl, 1ull),
+                                                        (unsigned long long)max_blocks);
+#define RT_LAUNCH_INTERSECT(P, CULL, SH)                                                        \
+    k_intersect<P, CULL, SH><<<g, kBlock, 0, s>>>(v.tree, v.tris, v.spheres, v.n_tris,          \
+                                                  v.n_spheres, q, count, out_t, out_id, sh_thr, \
+                                                  stride, n_slabs, work, work_next, dynamic)
+    if (sh_thr) {
+        if (v.cull) { if (wide) RT_LAUNCH_INTERSECT(2, true, true); else RT_LAUNCH_INTERSECT(1, true, true); }
+        else        { if (wide) RT_LAUNCH_INTERSECT(2, false, true); else RT_LAUNCH_INTERSECT(1, false, true); }
     } else {
-        if (wide) RT_LAUNCH_INTERSECT(2, false); else RT_LAUNCH_INTERSECT(1, false);
+        if (v.cull) { if (wide) RT_LAUNCH_INTERSECT(2, true, false); else RT_LAUNCH_INTERSECT(1, true, false); }
+        else        { if (wide) RT_LAUNCH_INTERSECT(2, false, false); else RT_LAUNCH_INTERSECT(1, false, false); }
     }
 #undef RT_LAUNCH_INTERSECT
 }
 
 void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
-                  int nl, int n_lights_total, int max_blocks)
+                  int nl, int n_lights_total, uint32_t stride, int max_blocks)
 {
     k_shade<<<grid_for(capacity, max_blocks), kBlock, 0, s>>>(v, cur, bounce, l0, nl,
-                                                              n_lights_total);
+                                                              n_lights_total, stride);
 }
 
 void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,
-                   int max_depth, int l0, int nl, int last_pass, int max_blocks)
+                   int max_depth, int l0, int nl, int last_pass, uint32_t stride, int max_blocks)
 {
     k_finish<<<grid_for(capacity, max_blocks), kBlock, 0, s>>>(v, cur, bounce, max_depth, l0, nl,
-                                                               last_pass);
+                                                               last_pass, stride);
 }
 
 void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,

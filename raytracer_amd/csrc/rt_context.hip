@@ -18,12 +18,36 @@ using namespace rt;
 
 namespace {
 
-constexpr uint32_t kMaxBatch = 1u << 21;     // paths per wavefront batch
+constexpr uint32_t kMaxBatch = 1u << 21;     // paths in flight per context (all lanes)
+constexpr uint32_t kMinLanePixels = 1u << 16;   // below this a second lane is not worth its launches
 constexpr int kLightsPerPass = 64;           // bits of the per-path shadow mask
 
 thread_local std::string g_err;              // for calls that have no context yet
 
 } // namespace
+
+// A lane renders a fixed, contiguous range of this context's pixels on its own HIP stream
+// with its own queues and counters.  Lanes never touch the same pixel, so they need no
+// ordering among themselves; their kernels overlap, which is what fills the SIMDs a
+// traversal kernel leaves idle while its few heaviest chunks finish.
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint32_t lo = 0, hi = 0;             // local pixel range [lo, hi)
+    uint32_t batch = 0;                  // queue capacity (paths)
+    size_t shadow_cap = 0;               // shadow queue capacity (slots)
+    RayQueue rays[2]{}, shadow{};
+    float *hit_t = nullptr;
+    int32_t *hit_id = nullptr;
+    float *sh_thr = nullptr;
+    float *sh_contrib[3] = {nullptr, nullptr, nullptr};
+    Ctl *ctl = nullptr;
+    uint32_t isect_seq = 0;              // closest-hit launches so far (dispenser parity)
+    // chunk-order feedback (rt_kernels.h ChunkFeedback), one block per (batch, kind):
+    // kind 0 = primary rays of bounce 0, kind 1 = their shadow rays
+    struct Fb { uint32_t *heavy[2]; uint32_t *n_heavy; unsigned long long *total; uint8_t *flag[2]; size_t chunks; };
+    std::vector<Fb> fb;                  // [batch_index * 2 + kind]
+};
 
 struct rt_context {
     int device = 0;
@@ -37,8 +61,9 @@ struct rt_context {
     int rank = 0, world = 1, tile = 64;
     uint32_t n_local = 0;
     std::vector<uint32_t> h_pixmap;
-    uint32_t batch = 0;                  // queue capacity (paths)
-    size_t shadow_cap = 0;               // shadow queue capacity (rays)
+    std::vector<Lane> lanes;             // streams/events live as long as the context
+    int n_lanes = 1;                     // lanes in use for the current partition
+    int lanes_wanted = 4;
 
     bool have_scene = false, have_cam = false;
     int n_lights = 0;
@@ -46,8 +71,7 @@ struct rt_context {
     float geom_extent = 1.0f;            // max |coordinate| of the uploaded geometry
     int max_blocks = 2048;
 
-    DevView v{};
-    uint32_t isect_seq = 0;              // closest-hit launches so far (dispenser parity)
+    DevView v{};                         // scene + per-pixel state; queue fields = lane 0's
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
 
     // stats
@@ -142,29 +166,78 @@ void build_pixmap(rt_context *c)
     c->n_local = (uint32_t)c->h_pixmap.size();
 }
 
+int alloc_feedback(rt_context *c, Lane &L);
+
 int alloc_shadow(rt_context *c)
 {
-    // (re)size the shadow queue for the current batch size and light count
-    size_t need = (size_t)c->batch * (size_t)std::max(1, std::min(c->n_lights, kLightsPerPass));
-    if (need <= c->shadow_cap)
-        return RT_OK;
-    // shadow buffers live with the partition allocations; growing re-partitions lazily
-    int rc;
-    if ((rc = alloc_queue(c, c->part_allocs, c->v.shadow, need, false))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, c->v.sh_thr, need))) return rc;
-    for (int k = 0; k < 3; k++)
-        if ((rc = dalloc(c, c->part_allocs, c->v.sh_contrib[k], need))) return rc;
-    c->shadow_cap = need;
+    // (re)size every lane's shadow queue for its batch size and the light count
+    for (int k = 0; k < c->n_lanes; k++) {
+        Lane &L = c->lanes[k];
+        size_t need = (size_t)L.batch * (size_t)std::max(1, std::min(c->n_lights, kLightsPerPass));
+        if (need <= L.shadow_cap)
+            continue;
+        // shadow buffers live with the partition allocations; outgrown ones stay until re-partition
+        int rc;
+        if ((rc = alloc_queue(c, c->part_allocs, L.shadow, need, false))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.sh_thr, need))) return rc;
+        for (int a = 0; a < 3; a++)
+            if ((rc = dalloc(c, c->part_allocs, L.sh_contrib[a], need))) return rc;
+        L.shadow_cap = need;
+    }
+    // the light count sets the number of shadow chunks: start the feedback afresh
+    for (int k = 0; k < c->n_lanes; k++) {
+        int rc = alloc_feedback(c, c->lanes[k]);
+        if (rc) return rc;
+    }
     return RT_OK;
+}
+
+// Feedback blocks of a lane, sized for the smallest chunk (128 rays) and the current lights.
+int alloc_feedback(rt_context *c, Lane &L)
+{
+    L.fb.clear();
+    const size_t span = L.hi - L.lo;
+    if (span == 0) return RT_OK;
+    const size_t n_batches = (span + L.batch - 1) / L.batch;
+    const size_t per_slab = ((size_t)L.batch + 127) / 128;
+    const size_t slabs = (size_t)std::max(1, std::min(c->n_lights, kLightsPerPass));
+    int rc;
+    for (size_t b = 0; b < n_batches; b++)
+        for (int kind = 0; kind < 2; kind++) {
+            Lane::Fb f{};
+            f.chunks = per_slab * (kind ? slabs : 1);
+            for (int s = 0; s < 2; s++) {
+                if ((rc = dalloc(c, c->part_allocs, f.heavy[s], f.chunks))) return rc;
+                if ((rc = dalloc(c, c->part_allocs, f.flag[s], f.chunks))) return rc;
+                RT_HIP(c, hipMemset(f.flag[s], 0, f.chunks));
+            }
+            if ((rc = dalloc(c, c->part_allocs, f.n_heavy, 2))) return rc;
+            if ((rc = dalloc(c, c->part_allocs, f.total, 2))) return rc;
+            RT_HIP(c, hipMemset(f.n_heavy, 0, 2 * sizeof(uint32_t)));
+            RT_HIP(c, hipMemset(f.total, 0, 2 * sizeof(unsigned long long)));
+            L.fb.push_back(f);
+        }
+    return RT_OK;
+}
+
+// The queue-side fields of a launch's DevView come from the lane.
+DevView lane_view(const rt_context *c, const Lane &L)
+{
+    DevView v = c->v;
+    v.rays[0] = L.rays[0]; v.rays[1] = L.rays[1];
+    v.shadow = L.shadow;
+    v.hit_t = L.hit_t; v.hit_id = L.hit_id;
+    v.sh_thr = L.sh_thr;
+    for (int a = 0; a < 3; a++) v.sh_contrib[a] = L.sh_contrib[a];
+    v.ctl = L.ctl;
+    return v;
 }
 
 int setup_partition(rt_context *c)
 {
     free_all(c->part_allocs);
-    c->shadow_cap = 0;
     build_pixmap(c);
     const size_t n = c->n_local;
-    c->batch = (uint32_t)std::min<size_t>(std::max<size_t>(n, 1), kMaxBatch);
     DevView &v = c->v;
     int rc;
     uint32_t *pixmap = nullptr;
@@ -182,12 +255,33 @@ int setup_partition(rt_context *c)
         if ((rc = dalloc(c, c->part_allocs, v.le[k], n))) return rc;
     }
     if ((rc = dalloc(c, c->part_allocs, v.bounce_draw, n))) return rc;
-    const size_t b = c->batch;
-    for (int k = 0; k < 2; k++)
-        if ((rc = alloc_queue(c, c->part_allocs, v.rays[k], b, true))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, v.hit_t, b))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, v.hit_id, b))) return rc;
+
+    // lanes: contiguous pixel ranges cut at 64x64-tile boundaries (4096 local indices)
+    int K = (int)std::min<size_t>((size_t)std::max(1, c->lanes_wanted), std::max<size_t>(1, n / kMinLanePixels));
+    K = std::min<int>(K, (int)c->lanes.size());
+    c->n_lanes = K;
+    for (int k = 0; k < K; k++) {
+        Lane &L = c->lanes[k];
+        auto cut = [&](int i) -> uint32_t {
+            if (i <= 0) return 0u;
+            if (i >= K) return (uint32_t)n;
+            return (uint32_t)((n * (size_t)i / (size_t)K) / 4096u * 4096u);
+        };
+        L.lo = cut(k);
+        L.hi = cut(k + 1);
+        const size_t span = L.hi - L.lo;
+        L.batch = (uint32_t)std::min<size_t>(std::max<size_t>(span, 1), std::max<uint32_t>(kMaxBatch / (uint32_t)K, 1u << 18));
+        L.shadow_cap = 0;
+        L.isect_seq = 0;
+        for (int q = 0; q < 2; q++)
+            if ((rc = alloc_queue(c, c->part_allocs, L.rays[q], L.batch, true))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.hit_t, (size_t)L.batch))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.hit_id, (size_t)L.batch))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.ctl, 1))) return rc;
+        RT_HIP(c, hipMemset(L.ctl, 0, sizeof(Ctl)));
+    }
     if ((rc = alloc_shadow(c))) return rc;
+    c->v = lane_view(c, c->lanes[0]);
     return RT_OK;
 }
 
@@ -230,23 +324,24 @@ void resolve_events(rt_context *c)
     c->ev_used = 0;
 }
 
-// One closest-hit launch, optionally bracketed by HIP events on the launch stream.
+// One closest-hit launch on a lane, optionally bracketed by HIP events on the lane's stream.
 // sh_thr != nullptr: shadow form over n_slabs light slabs of `stride` slots.
-void timed_intersect(rt_context *c, const RayQueue &q, const uint32_t *count, uint32_t cap,
-                     float *out_t, int32_t *out_id, float *sh_thr = nullptr, uint32_t stride = 0,
-                     uint32_t n_slabs = 1)
+void timed_intersect(rt_context *c, Lane &L, const DevView &v, const RayQueue &q,
+                     const uint32_t *count, uint32_t cap, float *out_t, int32_t *out_id,
+                     float *sh_thr = nullptr, uint32_t stride = 0, uint32_t n_slabs = 1,
+                     const ChunkFeedback *fb = nullptr)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         e0 = next_event(c);
         e1 = next_event(c);
     }
-    if (e0) (void)hipEventRecord(e0, c->stream);
-    launch_intersect(c->stream, c->v, q, count, cap, out_t, out_id, sh_thr, stride, n_slabs,
-                     c->max_blocks, &c->v.ctl->work[c->isect_seq & 1u],
-                     &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
-    c->isect_seq++;
-    if (e1) (void)hipEventRecord(e1, c->stream);
+    if (e0) (void)hipEventRecord(e0, L.stream);
+    launch_intersect(L.stream, v, q, count, cap, out_t, out_id, sh_thr, stride, n_slabs,
+                     c->max_blocks, L.ctl->work[L.isect_seq & 1u],
+                     L.ctl->work[(L.isect_seq + 1u) & 1u], fb);
+    L.isect_seq++;
+    if (e1) (void)hipEventRecord(e1, L.stream);
     c->launches++;
 }
 
@@ -298,8 +393,16 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
         return fail(nullptr, RT_ERR_DEVICE, m);
     }
     c->max_blocks = std::max(1, prop.multiProcessorCount) * 8;
-    int rc = dalloc(c, c->allocs, c->v.ctl, 1);
-    if (rc == RT_OK && hipMemset(c->v.ctl, 0, sizeof(Ctl)) != hipSuccess) rc = RT_ERR_DEVICE;
+    if (const char *e = std::getenv("RT_LANES")) c->lanes_wanted = std::max(1, std::min(8, std::atoi(e)));
+    int rc = RT_OK;
+    c->lanes.resize((size_t)c->lanes_wanted);
+    for (Lane &L : c->lanes) {
+        if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&L.done, hipEventDisableTiming) != hipSuccess) {
+            rc = fail(c, RT_ERR_DEVICE, "rt_create: could not create lane streams");
+            break;
+        }
+    }
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -319,6 +422,11 @@ extern "C" int rt_destroy(rt_context *c)
     free_all(c->part_allocs);
     free_all(c->scene_allocs);
     free_all(c->allocs);
+    for (Lane &L : c->lanes) {
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_r0) (void)hipEventDestroy(c->ev_r0);
     if (c->ev_r1) (void)hipEventDestroy(c->ev_r1);
@@ -430,46 +538,73 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
         return fail(c, RT_ERR_STATE, "rt_render needs rt_upload_scene and rt_set_camera first");
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
-    DevView &v = c->v;
     const int L = c->n_lights;
     const int n_pass = std::max(1, (L + kLightsPerPass - 1) / kLightsPerPass);
-    hipStream_t s = c->stream;
-    RT_HIP(c, hipEventRecord(c->ev_r0, s));
+    const bool use_fb = c->v.cull && c->v.tree.top >= 3;      // same test as the launcher's `dynamic`
+    hipStream_t s0 = c->stream;
+    RT_HIP(c, hipEventRecord(c->ev_r0, s0));                 // fork: lanes start after the main stream
+    for (int k = 0; k < c->n_lanes; k++)
+        RT_HIP(c, hipStreamWaitEvent(c->lanes[k].stream, c->ev_r0, 0));
     for (int smp = 0; smp < n_samples; smp++) {
         c->cnt++;
-        v.cnt = c->cnt;
-        for (uint32_t p0 = 0; p0 < c->n_local; p0 += c->batch) {
-            const uint32_t n = std::min(c->batch, c->n_local - p0);
-            launch_ctl_begin(s, v.ctl, n);
-            launch_gen(s, v, p0, n);
-            int cur = 0;
-            for (int bounce = 0; bounce <= max_depth; bounce++) {
-                timed_intersect(c, v.rays[cur], &v.ctl->n_cur, n, v.hit_t, v.hit_id);
-                for (int pass = 0; pass < n_pass; pass++) {
-                    const int l0 = pass * kLightsPerPass;
-                    const int nl = std::max(0, std::min(kLightsPerPass, L - l0));
-                    launch_shade(s, v, n, cur, bounce, l0, nl, L, c->batch, c->max_blocks);
-                    if (nl > 0)         // shadow rays of this pass: nl light slabs of `batch` slots
-                        timed_intersect(c, v.shadow, &v.ctl->n_cur, n, nullptr, nullptr, v.sh_thr,
-                                        c->batch, (uint32_t)nl);
-                    launch_finish(s, v, n, cur, bounce, max_depth, l0, nl, pass == n_pass - 1,
-                                  c->batch, c->max_blocks);
+        for (int k = 0; k < c->n_lanes; k++) {
+            Lane &ln = c->lanes[k];
+            hipStream_t s = ln.stream;
+            DevView v = lane_view(c, ln);
+            v.cnt = c->cnt;
+            size_t bi = 0;
+            for (uint32_t p0 = ln.lo; p0 < ln.hi; p0 += ln.batch, bi++) {
+                const uint32_t n = std::min(ln.batch, ln.hi - p0);
+                // heavy-first chunk order from the previous sample (bounce 0, single light pass)
+                auto feedback = [&](int kind, ChunkFeedback &f) -> const ChunkFeedback * {
+                    if (n_pass != 1 || bi * 2 + kind >= ln.fb.size()) return nullptr;
+                    const Lane::Fb &b = ln.fb[bi * 2 + kind];
+                    const int r = c->cnt & 1, w = r ^ 1;
+                    f.heavy_r = b.heavy[r]; f.n_heavy_r = b.n_heavy + r; f.total_r = b.total + r; f.flag_r = b.flag[r];
+                    f.heavy_w = b.heavy[w]; f.n_heavy_w = b.n_heavy + w; f.total_w = b.total + w; f.flag_w = b.flag[w];
+                    (void)hipMemsetAsync(b.n_heavy + w, 0, sizeof(uint32_t), s);
+                    (void)hipMemsetAsync(b.total + w, 0, sizeof(unsigned long long), s);
+                    return &f;
+                };
+                ChunkFeedback f0{}, f1{};
+                launch_ctl_begin(s, v.ctl, n);
+                launch_gen(s, v, p0, n);
+                int cur = 0;
+                for (int bounce = 0; bounce <= max_depth; bounce++) {
+                    timed_intersect(c, ln, v, v.rays[cur], &v.ctl->n_cur, n, v.hit_t, v.hit_id, nullptr, 0,
+                                    1, bounce == 0 && use_fb ? feedback(0, f0) : nullptr);
+                    for (int pass = 0; pass < n_pass; pass++) {
+                        const int l0 = pass * kLightsPerPass;
+                        const int nl = std::max(0, std::min(kLightsPerPass, L - l0));
+                        launch_shade(s, v, n, cur, bounce, l0, nl, L, ln.batch, c->max_blocks);
+                        if (nl > 0)     // shadow rays of this pass: nl light slabs of `batch` slots
+                            timed_intersect(c, ln, v, v.shadow, &v.ctl->n_cur, n, nullptr, nullptr,
+                                            v.sh_thr, ln.batch, (uint32_t)nl,
+                                            bounce == 0 && use_fb ? feedback(1, f1) : nullptr);
+                        launch_finish(s, v, n, cur, bounce, max_depth, l0, nl, pass == n_pass - 1,
+                                      ln.batch, c->max_blocks);
+                    }
+                    launch_ctl_next_bounce(s, v.ctl);
+                    cur ^= 1;
                 }
-                launch_ctl_next_bounce(s, v.ctl);
-                cur ^= 1;
+                c->primary += n;
             }
-            c->primary += n;
         }
         c->samples += c->n_local;
-        // event pairs are resolved without disturbing the stream: only when the pool
+        // event pairs are resolved without disturbing the streams: only when the pool
         // would grow past a bound, or at the end of the call (which synchronises anyway)
         if (c->timing && c->ev_used > 32768) {
-            RT_HIP(c, hipStreamSynchronize(s));
+            for (int k = 0; k < c->n_lanes; k++)
+                RT_HIP(c, hipStreamSynchronize(c->lanes[k].stream));
             resolve_events(c);
         }
     }
-    RT_HIP(c, hipEventRecord(c->ev_r1, s));
-    RT_HIP(c, hipStreamSynchronize(s));          // cudaStreamSynchronize, kernel.cu:123
+    for (int k = 0; k < c->n_lanes; k++) {                   // join
+        RT_HIP(c, hipEventRecord(c->lanes[k].done, c->lanes[k].stream));
+        RT_HIP(c, hipStreamWaitEvent(s0, c->lanes[k].done, 0));
+    }
+    RT_HIP(c, hipEventRecord(c->ev_r1, s0));
+    RT_HIP(c, hipStreamSynchronize(s0));          // cudaStreamSynchronize, kernel.cu:123
     RT_HIP(c, hipGetLastError());
     resolve_events(c);
     float ms = 0.0f;
@@ -572,10 +707,11 @@ extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float 
         if (e == hipSuccess) e = hipMemcpyAsync(d_count, &un, 4, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
             launch_prepare_rays(s, q, d_org, d_dir, un);
+            Lane &L0 = c->lanes[0];
             launch_intersect(s, c->v, q, d_count, un, d_t, d_id, nullptr, 0, 1, c->max_blocks,
-                             &c->v.ctl->work[c->isect_seq & 1u],
-                             &c->v.ctl->work[(c->isect_seq + 1u) & 1u]);
-            c->isect_seq++;
+                             L0.ctl->work[L0.isect_seq & 1u], L0.ctl->work[(L0.isect_seq + 1u) & 1u],
+                             nullptr);
+            L0.isect_seq++;
             launch_ishit(s, d_t, d_hit, un);
             e = hipStreamSynchronize(s);
         }
@@ -617,12 +753,17 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
 {
     if (!c || !st) return fail(c, RT_ERR_INVALID, "NULL argument");
     RT_HIP(c, hipSetDevice(c->device));
-    Ctl h;
-    RT_HIP(c, hipMemcpy(&h, c->v.ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+    unsigned long long shadow_total = 0, bounce_total = 0;
+    for (int k = 0; k < c->n_lanes; k++) {
+        Ctl h;
+        RT_HIP(c, hipMemcpy(&h, c->lanes[k].ctl, sizeof(Ctl), hipMemcpyDeviceToHost));
+        shadow_total += h.shadow_total;
+        bounce_total += h.bounce_total;
+    }
     st->samples = c->samples;
     st->primary_rays = c->primary;
-    st->shadow_rays = h.shadow_total;
-    st->bounce_rays = h.bounce_total;
+    st->shadow_rays = shadow_total;
+    st->bounce_rays = bounce_total;
     st->intersect_launches = c->timing ? c->timed_launches : c->launches;
     st->intersect_ms = c->intersect_ms;
     st->render_ms = c->render_ms;
@@ -635,7 +776,10 @@ extern "C" int rt_reset_stats(rt_context *c)
     if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
     RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
-    RT_HIP(c, hipMemset(c->v.ctl, 0, sizeof(Ctl)));
+    for (int k = 0; k < c->n_lanes; k++) {
+        RT_HIP(c, hipMemset(c->lanes[k].ctl, 0, sizeof(Ctl)));
+        c->lanes[k].isect_seq = 0;
+    }
     c->samples = c->primary = c->launches = c->timed_launches = 0;
     c->intersect_ms = c->render_ms = 0.0;
     return RT_OK;

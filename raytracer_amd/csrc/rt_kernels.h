@@ -13,10 +13,9 @@ struct Ctl {
     uint32_t n_cur;        // active paths of the current bounce
     uint32_t n_next;       // survivors pushed for the next bounce
     uint32_t pad[2];
-    // Chunk dispensers of the closest-hit kernel (one per launch parity): waves draw
-    // 64*R-ray chunks with atomicAdd; launch k uses work[k & 1] and zeroes the other.
-    uint32_t work[2];
-    uint32_t pad2[2];
+    // Chunk dispensers of the closest-hit kernel: [0] waves draw ordinary chunks, [1] blocks
+    // draw the heavy ones.  Launch k uses pair k & 1 and zeroes the other for launch k + 1.
+    uint32_t work[2][2];
     unsigned long long shadow_total;   // shadow rays cast since rt_reset_stats
     unsigned long long bounce_total;   // bounce (>= 1) rays traced since rt_reset_stats
 };
@@ -36,6 +35,24 @@ struct TreeView {
     int top;               // the top level is one group
     int n_groups0;         // number of 4-triangle groups of level 0
     float extent;          // rays whose origin leaves [-extent, extent]^3 are never culled
+};
+
+// Chunk-order feedback of the closest-hit kernel (deep trees only).  A chunk's cost is
+// stable from one progressive sample to the next (same pixels, same slots), so each
+// launch records which chunks were heavy and the next launch of the same queue hands
+// those out FIRST: the kernel then ends with cheap chunks instead of waiting for a
+// straggler that was dispensed last.  Two sets alternate by sample parity: `r` was
+// written by the previous sample, `w` is written now.  Only an ordering hint -- every
+// chunk is still processed exactly once.
+struct ChunkFeedback {
+    const uint32_t *heavy_r;             // chunk ids that were heavy
+    const uint32_t *n_heavy_r;
+    const unsigned long long *total_r;   // summed cost of all chunks
+    const uint8_t *flag_r;               // per chunk: 1 = in heavy_r
+    uint32_t *heavy_w;
+    uint32_t *n_heavy_w;
+    unsigned long long *total_w;
+    uint8_t *flag_w;
 };
 
 struct DevView {
@@ -79,7 +96,8 @@ void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n);
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
                       uint32_t capacity, float *out_t, int32_t *out_id, float *sh_thr,
                       uint32_t stride, uint32_t n_slabs, int max_blocks, uint32_t *work,
-                      uint32_t *work_next);
+                      uint32_t *work_next, const ChunkFeedback *fb);
+uint32_t intersect_rays_per_chunk(const DevView &v, uint32_t capacity);
 void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
                   int nl, int n_lights_total, uint32_t stride, int max_blocks);
 void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,

@@ -67,20 +67,35 @@ __global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t
 // Scene::hit (Scene.cu:8-67): the closest of all primitives the reference's scan would
 // accept -- min over (t, reference index) -- found without visiting most of them.
 //
-// A wave owns 64 * 2P rays (P packed pairs per lane).  The triangle side is
-// wave-uniform: node and triangle records come through the scalar data path, one
-// aligned 64-byte block (s_load_dwordx16) per group of four nodes / per triangle, and
-// sit in SGPRs as operands of packed fp32 VALU ops.  Traversal of the implicit 4-ary
-// box tree is stackless: the state is (level, group index, 4 pending-child bits per
-// level packed in one 64-bit scalar), all in SGPRs; a group is expanded when any ray
-// of the wave may still hit below it.  The tests of node_test() only ever discard
-// (ray, triangle) pairs Triangle::hit would reject, so the result is the scan's.
+// A wave owns a chunk of 64 * 2P rays (P packed pairs per lane).  The triangle side is
+// wave-uniform: box groups (96 B) and triangle records (64 B) come through the scalar data
+// path and sit in SGPRs as operands of packed fp32 VALU ops.  Traversal of the implicit
+// 4-ary box tree is stackless: (level, group index) in SGPRs plus one VGPR whose lane l
+// holds level l's pending children; a group is expanded when any ray of the wave may
+// still hit below it, nearest child first.  node_test() only ever discards (ray,
+// triangle) pairs Triangle::hit would reject, so the result is the scan's.
 // CULL = false visits every triangle (validation mode, rt_set_culling(ctx, 0)).
+//
+// Because the result is a min over (t, index), it does not depend on who finds what
+// first.  That is what lets the four waves of a block share ONE chunk when the previous
+// sample found it heavy (COOP): every wave holds the chunk's rays, walks the top of the
+// tree, and descends only into the level-kSplitLevel subtrees a hash assigns to it;
+// hits are merged with a 64-bit ds_min on (t bits, index + 1) per ray in LDS, which every
+// wave re-reads at each expansion so that all of them prune against the common best.
+// A single wave retires a heavy chunk at about a microsecond per node group, and a kernel
+// cannot end before its longest chunk does.
 
 template <int P>
 struct WaveRays {
     RayPair r[P];
 };
+
+constexpr int kSplitLevel = 2;       // cooperative chunks: subtrees of 4^(kSplitLevel+1) triangles
+
+__device__ __forceinline__ unsigned long long pack_hit(float t, int32_t id)
+{
+    return ((unsigned long long)__float_as_uint(t) << 32) | (uint32_t)(id + 1);
+}
 
 template <int P>
 __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, uint32_t node,
@@ -120,6 +135,27 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
     a = lo; b = hi;
 }
 
+struct IsectArgs {
+    TreeView tv;
+    const TriRec *tris;
+    const SphereRec *spheres;
+    int n_tris, n_spheres;
+    RayQueue q;
+    float *out_t;
+    int32_t *out_id;
+    float *sh_thr;
+    uint32_t stride;
+    uint32_t count, chunks_per_slab;
+    bool occlusion;
+    uint32_t lvloff;                 // lane l: first group of level l
+    uint32_t heavy_cost;             // cost from which a chunk counts as heavy (feedback)
+    ChunkFeedback fb;
+    bool feedback;
+};
+
+// One chunk.  COOP: called by all four waves of the block with the same chunk; s_best is
+// the block's LDS merge array (64 * 2P entries), s_cost its cost accumulator.
+//
 // SHADOW = true is the shadow-ray form of the same traversal (Scene.cu:224-227): the queue
 // holds n_slabs slabs of `stride` slots, slot j * stride + i = the ray from path i towards
 // light j (light-major, so a chunk's rays head for ONE light from neighbouring pixels);
@@ -129,6 +165,269 @@ __device__ __forceinline__ void cswap(uint32_t &a, uint32_t &b)
 // ray stops at the first hit below thr - m, m covering the difference between t and the
 // reference's |fl(o + t d) - o|; inside the band the true closest hit decides, exactly as
 // the reference computes it.
+template <int P, bool CULL, bool SHADOW, bool COOP>
+__device__ __forceinline__ void process_chunk(const IsectArgs &A, uint32_t chunk, uint32_t lane,
+                                              uint32_t wib, unsigned long long *s_best,
+                                              uint32_t *s_cost)
+{
+    constexpr uint32_t R = 2 * P;
+    const TreeView &tv = A.tv;
+    const uint32_t count = A.count;
+    const uint32_t slab = SHADOW ? chunk / A.chunks_per_slab : 0u;
+    const uint32_t base = (chunk - slab * A.chunks_per_slab) * 64u * R;     // path position
+    const uint32_t qbase = slab * A.stride + base;                         // queue position
+    const RayQueue &q = A.q;
+    uint32_t cost = 0;                           // node groups expanded + triangles tested
+    WaveRays<P> w;
+    float thr[R];
+    bool live[R];
+    bool any_live = false;
+#pragma unroll
+    for (int k = 0; k < (int)R; k++) {
+        live[k] = base + k * 64u + lane < count;
+        thr[k] = 0.0f;
+        if (SHADOW) {
+            thr[k] = live[k] ? A.sh_thr[qbase + k * 64u + lane] : -1.0f;
+            live[k] = thr[k] >= 0.0f;
+        }
+        any_live |= live[k];
+    }
+    if (SHADOW && !__ballot(any_live)) {         // a chunk of empty slots (e.g. sky pixels)
+        if (A.feedback && lane == 0 && (!COOP || wib == 0))
+            A.fb.flag_w[chunk] = 0;
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        RayPair &r = w.r[p];
+        uint32_t i0 = qbase + (2 * p) * 64u + lane, i1 = i0 + 64u;
+        // dead lanes: parked far away with an empty t window
+        float o0[3] = {0.0f, 1e18f, 0.0f}, d0[3] = {1.0f, 0.0f, 0.0f};
+        float o1[3] = {0.0f, 1e18f, 0.0f}, d1[3] = {1.0f, 0.0f, 0.0f};
+        float b0 = 0.0f, b1 = 0.0f;
+        if (live[2 * p]) {
+            o0[0] = q.ox[i0]; o0[1] = q.oy[i0]; o0[2] = q.oz[i0];
+            d0[0] = q.dx[i0]; d0[1] = q.dy[i0]; d0[2] = q.dz[i0];
+            b0 = kInf;                                   // IntersectRecord(): t = INF
+        }
+        if (live[2 * p + 1]) {
+            o1[0] = q.ox[i1]; o1[1] = q.oy[i1]; o1[2] = q.oz[i1];
+            d1[0] = q.dx[i1]; d1[1] = q.dy[i1]; d1[2] = q.dz[i1];
+            b1 = kInf;
+        }
+        r.stop = f2{-1.0f, -1.0f};
+        if (A.occlusion) {
+            float m0 = 1e-4f * (fabsf(thr[2 * p]) + fabsf(o0[0]) + fabsf(o0[1]) + fabsf(o0[2])) + 1e-6f;
+            float m1 = 1e-4f * (fabsf(thr[2 * p + 1]) + fabsf(o1[0]) + fabsf(o1[1]) + fabsf(o1[2])) + 1e-6f;
+            if (live[2 * p]) { b0 = fminf(kInf, thr[2 * p] + m0); r.stop.x = thr[2 * p] - m0; }
+            if (live[2 * p + 1]) { b1 = fminf(kInf, thr[2 * p + 1] + m1); r.stop.y = thr[2 * p + 1] - m1; }
+        }
+        r.ox = f2{o0[0], o1[0]}; r.oy = f2{o0[1], o1[1]}; r.oz = f2{o0[2], o1[2]};
+        r.dx = f2{d0[0], d1[0]}; r.dy = f2{d0[1], d1[1]}; r.dz = f2{d0[2], d1[2]};
+        r.ix = f2{slab_inv(d0[0]), slab_inv(d1[0])};
+        r.iy = f2{slab_inv(d0[1]), slab_inv(d1[1])};
+        r.iz = f2{slab_inv(d0[2]), slab_inv(d1[2])};
+        r.best = f2{b0, b1};
+        r.bestp = r.best * kBestInfl;
+        r.idx = -1; r.idy = -1;
+        const float E = tv.extent;
+        r.wildx = live[2 * p] & !((fabsf(o0[0]) <= E) & (fabsf(o0[1]) <= E) & (fabsf(o0[2]) <= E) &
+                                  (fabsf(d0[0]) <= 2.0f) & (fabsf(d0[1]) <= 2.0f) & (fabsf(d0[2]) <= 2.0f));
+        r.wildy = live[2 * p + 1] & !((fabsf(o1[0]) <= E) & (fabsf(o1[1]) <= E) & (fabsf(o1[2]) <= E) &
+                                      (fabsf(d1[0]) <= 2.0f) & (fabsf(d1[1]) <= 2.0f) & (fabsf(d1[2]) <= 2.0f));
+    }
+
+    // cooperative form: the block's merge array starts from every ray's own start value
+    unsigned long long pub[R];                   // what this wave last saw or wrote per ray
+    if (COOP) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            pub[2 * p] = pack_hit(w.r[p].best.x, -1);
+            pub[2 * p + 1] = pack_hit(w.r[p].best.y, -1);
+            if (wib == 0) {
+                s_best[(2 * p) * 64 + lane] = pub[2 * p];
+                s_best[(2 * p + 1) * 64 + lane] = pub[2 * p + 1];
+            }
+        }
+        if (threadIdx.x == 0) *s_cost = 0;
+        __syncthreads();
+    }
+    // take over what the other waves have found (COOP): min over (t, index)
+    auto merge_in = [&]() {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            RayPair &r = w.r[p];
+            unsigned long long vx = s_best[(2 * p) * 64 + lane], vy = s_best[(2 * p + 1) * 64 + lane];
+            if (vx < pack_hit(r.best.x, r.idx)) {
+                r.best.x = __uint_as_float((uint32_t)(vx >> 32));
+                r.idx = (int32_t)(uint32_t)vx - 1;
+                r.bestp.x = r.best.x < r.stop.x ? -1.0f : r.best.x * kBestInfl;
+                if (r.best.x < r.stop.x) r.wildx = false;
+            }
+            if (vy < pack_hit(r.best.y, r.idy)) {
+                r.best.y = __uint_as_float((uint32_t)(vy >> 32));
+                r.idy = (int32_t)(uint32_t)vy - 1;
+                r.bestp.y = r.best.y < r.stop.y ? -1.0f : r.best.y * kBestInfl;
+                if (r.best.y < r.stop.y) r.wildy = false;
+            }
+            pub[2 * p] = vx < pub[2 * p] ? vx : pub[2 * p];
+            pub[2 * p + 1] = vy < pub[2 * p + 1] ? vy : pub[2 * p + 1];
+        }
+    };
+    // publish this wave's improvements (COOP)
+    auto merge_out = [&]() {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            RayPair &r = w.r[p];
+            unsigned long long mx = pack_hit(r.best.x, r.idx), my = pack_hit(r.best.y, r.idy);
+            if (mx < pub[2 * p]) { atomicMin(&s_best[(2 * p) * 64 + lane], mx); pub[2 * p] = mx; }
+            if (my < pub[2 * p + 1]) { atomicMin(&s_best[(2 * p + 1) * 64 + lane], my); pub[2 * p + 1] = my; }
+        }
+    };
+
+    if (CULL) {
+        int l = tv.top;
+        uint32_t g = 0;
+        uint32_t state = 0;                  // lane l: pending children of level l
+        uint32_t lanebits = 0;               // level 0: which (triangle, ray) pairs passed
+        bool expand = true;
+        const bool split = COOP && tv.top > kSplitLevel;
+        for (;;) {
+            if (expand) {
+                cost++;
+                if (COOP) merge_in();
+                const NodeGroup G = tv.groups[lane_get(A.lvloff, l) + g];
+                uint32_t key[4], lb = 0, n_pass = 0;
+#pragma unroll
+                for (int j = 0; j < kTreeArity; j++) {
+                    bool any = false;
+                    float near = 3.0e38f;    // smallest entry parameter among this lane's passing rays
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        bool px, py;
+                        float ex, ey;
+                        node_test(w.r[p], G.lo[0][j], G.lo[1][j], G.lo[2][j], G.hi[0][j], G.hi[1][j],
+                                  G.hi[2][j], px, py, ex, ey);
+                        any |= px | py;
+                        near = fminf(near, fminf(px ? ex : 3.0e38f, py ? ey : 3.0e38f));
+                        lb |= ((uint32_t)px << (j * 2 * P + 2 * p)) | ((uint32_t)py << (j * 2 * P + 2 * p + 1));
+                    }
+                    // lo > hi (padding, or a triangle Model.cu:99 always rejects) is dead
+                    // for every ray, including the unculled ones
+                    unsigned long long b = __ballot(any);
+                    key[j] = 0xffffffffu;
+                    bool take = b && !(G.lo[0][j] > G.hi[0][j]);
+                    if (take && split && l == kSplitLevel + 1) {
+                        // the subtree below this child belongs to one wave of the block
+                        uint32_t node = g * kTreeArity + (uint32_t)j;
+                        take = ((node * 2654435761u) >> 30) == wib;
+                    }
+                    if (take) {
+                        // visit order: entry parameter of the first passing lane (a coherent
+                        // wave's rays agree on it closely enough); the child index rides in
+                        // the two low mantissa bits
+                        float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                            __builtin_bit_cast(int, near), __builtin_ctzll(b)));
+                        key[j] = (__builtin_bit_cast(uint32_t, e) & ~3u) | (uint32_t)j;
+                        n_pass++;
+                    }
+                }
+                cswap(key[0], key[1]); cswap(key[2], key[3]);
+                cswap(key[0], key[2]); cswap(key[1], key[3]);
+                cswap(key[1], key[2]);
+                uint32_t word = (key[0] & 3u) | (key[1] & 3u) << 2 | (key[2] & 3u) << 4 |
+                                (key[3] & 3u) << 6 | n_pass << 8;
+                state = lane_set(state, l, word);
+                if (l == 0)
+                    lanebits = lb;
+                expand = false;
+            }
+            uint32_t word = lane_get(state, l);
+            if ((word >> 8) == 0) {
+                if (l == tv.top)
+                    break;
+                l++;
+                g >>= 2;
+                continue;
+            }
+            int j = (int)(word & 3u);
+            state = lane_set(state, l, ((word & 0xffu) >> 2) | ((word >> 8) - 1u) << 8);
+            uint32_t node = g * kTreeArity + (uint32_t)j;
+            if (l == 0) {
+                cost++;
+                test_triangle<P>(A.tris, node, w, lanebits, j);
+                if (COOP) merge_out();
+            } else {
+                l--;
+                g = node;
+                expand = true;
+            }
+        }
+    } else {
+        for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
+            test_triangle<P>(A.tris, node, w, 0xffffffffu, 0);
+    }
+
+    if (COOP) {
+        if (lane == 0) atomicAdd(s_cost, cost);
+        __syncthreads();
+        merge_in();                              // the block's final answer
+        cost = *s_cost;
+        __syncthreads();                         // s_best / s_cost are free for the next chunk
+        if (wib != 0)
+            return;                              // one wave writes the chunk's results
+    }
+    if (A.feedback && lane == 0) {
+        const bool heavy = cost >= A.heavy_cost;
+        A.fb.flag_w[chunk] = heavy ? 1 : 0;
+        atomicAdd(A.fb.total_w, (unsigned long long)cost);
+        if (heavy)
+            A.fb.heavy_w[atomicAdd(A.fb.n_heavy_w, 1u)] = chunk;
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        RayPair &r = w.r[p];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint32_t i = qbase + (2 * p + h) * 64u + lane;
+            v3 o = mk3(h ? r.ox.y : r.ox.x, h ? r.oy.y : r.oy.x, h ? r.oz.y : r.oz.x);
+            v3 d = mk3(h ? r.dx.y : r.dx.x, h ? r.dy.y : r.dy.x, h ? r.dz.y : r.dz.x);
+            float best = h ? r.best.y : r.best.x;
+            int32_t id = h ? r.idy : r.idx;
+            for (int s = 0; s < A.n_spheres; s++) {       // quadrics come last (Scene.cu:31-37)
+                float t;
+                if (sphere_hit(A.spheres[s], o, d, best, t)) {
+                    best = t;
+                    id = A.n_tris + s;
+                }
+            }
+            if (!live[2 * p + h])
+                continue;
+            if (SHADOW) {
+                // Scene.cu:225-227: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
+                // (H3: `lightidx == idx` restated as never true for point lights)
+                bool blocked = false;
+                if (scene_ishit(best) && id >= 0) {
+                    Ray sr; sr.o = o; sr.d = d;
+                    v3 hp = id < A.n_tris ? ray_pos(sr, best)
+                                          : hit_pos_sphere(A.spheres[id - A.n_tris], sr, best);
+                    blocked = length(sub(hp, o)) < thr[2 * p + h];
+                }
+                A.sh_thr[i] = blocked ? 1.0f : 0.0f;
+            } else {
+                A.out_t[i] = best;
+                A.out_id[i] = id;
+            }
+        }
+    }
+}
+
+// Over a deep tree a chunk costs anything from a handful of node tests (rays into empty
+// space) to hundreds, so waves draw chunks from a dispenser (`dynamic`); over a shallow one
+// every chunk is cheap, the same-address atomic would be the bottleneck, and waves stride
+// the queue instead.  With feedback (ChunkFeedback) the chunks the previous sample found
+// heavy go first, one per BLOCK (cooperative form); the rest follow, one per wave.  Every
+// wave leaves as soon as its next chunk lies past the end.
 template <int P, bool CULL, bool SHADOW>
 __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec *__restrict__ tris,
                                                       const SphereRec *__restrict__ spheres,
@@ -139,29 +438,58 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
                                                       float *__restrict__ sh_thr, uint32_t stride,
                                                       uint32_t n_slabs,
                                                       uint32_t *__restrict__ work,
-                                                      uint32_t *__restrict__ work_next, int dynamic)
+                                                      uint32_t *__restrict__ work_next, int dynamic,
+                                                      ChunkFeedback fb)
 {
     constexpr uint32_t R = 2 * P;
-    const uint32_t count = *count_ptr;
-    const uint32_t chunks_per_slab = (count + 64u * R - 1u) / (64u * R);
-    const uint32_t n_chunks = chunks_per_slab * (SHADOW ? n_slabs : 1u);
-    const bool occlusion = SHADOW && n_spheres == 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        *work_next = 0u;                 // the next launch's dispenser (stream-ordered after us)
-    const uint32_t lvloff = tv.level_off[lane & (kMaxLevels - 1)];
+    __shared__ unsigned long long s_best[64 * R];
+    __shared__ uint32_t s_cost, s_chunk;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    IsectArgs A;
+    A.tv = tv; A.tris = tris; A.spheres = spheres; A.n_tris = n_tris; A.n_spheres = n_spheres;
+    A.q = q; A.out_t = out_t; A.out_id = out_id; A.sh_thr = sh_thr; A.stride = stride;
+    A.count = *count_ptr;
+    A.chunks_per_slab = (A.count + 64u * R - 1u) / (64u * R);
+    const uint32_t n_chunks = A.chunks_per_slab * (SHADOW ? n_slabs : 1u);
+    A.occlusion = SHADOW && n_spheres == 0;
+    A.lvloff = tv.level_off[lane & (kMaxLevels - 1)];
+    A.fb = fb;
+    A.feedback = dynamic && fb.flag_w != nullptr;
+    A.heavy_cost = 0xffffffffu;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        work_next[0] = 0u;               // the next launch's dispensers (stream-ordered after us)
+        work_next[1] = 0u;
+    }
+    uint32_t n_heavy = 0;
+    if (A.feedback) {
+        n_heavy = *fb.n_heavy_r;
+        unsigned long long total = *fb.total_r;
+        if (total)
+            A.heavy_cost = (uint32_t)std::max<unsigned long long>(4ull * total / std::max(n_chunks, 1u), 48ull);
+    }
+
+    // phase 1: the previous sample's heavy chunks, one per block
+    if (CULL && n_heavy) {
+        for (;;) {
+            if (threadIdx.x == 0)
+                s_chunk = atomicAdd(&work[1], 1u);
+            __syncthreads();
+            const uint32_t d = s_chunk;
+            __syncthreads();
+            if (d >= n_heavy)
+                break;
+            process_chunk<P, CULL, SHADOW, true>(A, fb.heavy_r[d], lane, wib, s_best, &s_cost);
+        }
+    }
+
+    // phase 2: everything else, one per wave
     const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
     uint32_t next_chunk = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    // Over a deep tree a chunk costs anything from a handful of node tests (rays into
-    // empty space) to thousands, so waves draw chunks from a dispenser (`dynamic`);
-    // over a shallow one every chunk is cheap, the same-address atomic would be the
-    // bottleneck, and waves stride the queue instead.  Either way every wave leaves as
-    // soon as its next chunk lies past the end.
     for (;;) {
         uint32_t chunk = 0;
         if (dynamic) {
             if (lane == 0)
-                chunk = atomicAdd(work, 1u);
+                chunk = atomicAdd(&work[0], 1u);
             chunk = __builtin_amdgcn_readfirstlane(chunk);
         } else {
             chunk = next_chunk;
@@ -169,173 +497,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
         }
         if (chunk >= n_chunks)
             break;
-        const uint32_t slab = SHADOW ? chunk / chunks_per_slab : 0u;
-        const uint32_t base = (chunk - slab * chunks_per_slab) * 64u * R;   // path position
-        const uint32_t qbase = slab * stride + base;                       // queue position
-        WaveRays<P> w;
-        float thr[R];
-        bool live[R];
-        bool any_live = false;
-#pragma unroll
-        for (int k = 0; k < (int)R; k++) {
-            live[k] = base + k * 64u + lane < count;
-            thr[k] = 0.0f;
-            if (SHADOW) {
-                thr[k] = live[k] ? sh_thr[qbase + k * 64u + lane] : -1.0f;
-                live[k] = thr[k] >= 0.0f;
-            }
-            any_live |= live[k];
-        }
-        if (SHADOW && !__ballot(any_live))
-            continue;                            // a chunk of empty slots (e.g. sky pixels)
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            RayPair &r = w.r[p];
-            uint32_t i0 = qbase + (2 * p) * 64u + lane, i1 = i0 + 64u;
-            // dead lanes: parked far away with an empty t window
-            float o0[3] = {0.0f, 1e18f, 0.0f}, d0[3] = {1.0f, 0.0f, 0.0f};
-            float o1[3] = {0.0f, 1e18f, 0.0f}, d1[3] = {1.0f, 0.0f, 0.0f};
-            float b0 = 0.0f, b1 = 0.0f;
-            if (live[2 * p]) {
-                o0[0] = q.ox[i0]; o0[1] = q.oy[i0]; o0[2] = q.oz[i0];
-                d0[0] = q.dx[i0]; d0[1] = q.dy[i0]; d0[2] = q.dz[i0];
-                b0 = kInf;                                   // IntersectRecord(): t = INF
-            }
-            if (live[2 * p + 1]) {
-                o1[0] = q.ox[i1]; o1[1] = q.oy[i1]; o1[2] = q.oz[i1];
-                d1[0] = q.dx[i1]; d1[1] = q.dy[i1]; d1[2] = q.dz[i1];
-                b1 = kInf;
-            }
-            r.stop = f2{-1.0f, -1.0f};
-            if (occlusion) {
-                float m0 = 1e-4f * (fabsf(thr[2 * p]) + fabsf(o0[0]) + fabsf(o0[1]) + fabsf(o0[2])) + 1e-6f;
-                float m1 = 1e-4f * (fabsf(thr[2 * p + 1]) + fabsf(o1[0]) + fabsf(o1[1]) + fabsf(o1[2])) + 1e-6f;
-                if (live[2 * p]) { b0 = fminf(kInf, thr[2 * p] + m0); r.stop.x = thr[2 * p] - m0; }
-                if (live[2 * p + 1]) { b1 = fminf(kInf, thr[2 * p + 1] + m1); r.stop.y = thr[2 * p + 1] - m1; }
-            }
-            r.ox = f2{o0[0], o1[0]}; r.oy = f2{o0[1], o1[1]}; r.oz = f2{o0[2], o1[2]};
-            r.dx = f2{d0[0], d1[0]}; r.dy = f2{d0[1], d1[1]}; r.dz = f2{d0[2], d1[2]};
-            r.ix = f2{slab_inv(d0[0]), slab_inv(d1[0])};
-            r.iy = f2{slab_inv(d0[1]), slab_inv(d1[1])};
-            r.iz = f2{slab_inv(d0[2]), slab_inv(d1[2])};
-            r.best = f2{b0, b1};
-            r.bestp = r.best * kBestInfl;
-            r.idx = -1; r.idy = -1;
-            const float E = tv.extent;
-            r.wildx = live[2 * p] & !((fabsf(o0[0]) <= E) & (fabsf(o0[1]) <= E) & (fabsf(o0[2]) <= E) &
-                                      (fabsf(d0[0]) <= 2.0f) & (fabsf(d0[1]) <= 2.0f) & (fabsf(d0[2]) <= 2.0f));
-            r.wildy = live[2 * p + 1] & !((fabsf(o1[0]) <= E) & (fabsf(o1[1]) <= E) & (fabsf(o1[2]) <= E) &
-                                          (fabsf(d1[0]) <= 2.0f) & (fabsf(d1[1]) <= 2.0f) & (fabsf(d1[2]) <= 2.0f));
-        }
-
-        if (CULL) {
-            int l = tv.top;
-            uint32_t g = 0;
-            uint32_t state = 0;                  // lane l: pending children of level l
-            uint32_t lanebits = 0;               // level 0: which (triangle, ray) pairs passed
-            bool expand = true;
-            for (;;) {
-                if (expand) {
-                    const NodeGroup G = tv.groups[lane_get(lvloff, l) + g];
-                    uint32_t key[4], lb = 0, n_pass = 0;
-#pragma unroll
-                    for (int j = 0; j < kTreeArity; j++) {
-                        bool any = false;
-                        float near = 3.0e38f;    // smallest entry parameter among this lane's passing rays
-#pragma unroll
-                        for (int p = 0; p < P; p++) {
-                            bool px, py;
-                            float ex, ey;
-                            node_test(w.r[p], G.lo[0][j], G.lo[1][j], G.lo[2][j], G.hi[0][j], G.hi[1][j],
-                                      G.hi[2][j], px, py, ex, ey);
-                            any |= px | py;
-                            near = fminf(near, fminf(px ? ex : 3.0e38f, py ? ey : 3.0e38f));
-                            lb |= ((uint32_t)px << (j * 2 * P + 2 * p)) | ((uint32_t)py << (j * 2 * P + 2 * p + 1));
-                        }
-                        // lo > hi (padding, or a triangle Model.cu:99 always rejects) is dead
-                        // for every ray, including the unculled ones
-                        unsigned long long b = __ballot(any);
-                        key[j] = 0xffffffffu;
-                        if (b && !(G.lo[0][j] > G.hi[0][j])) {
-                            // visit order: entry parameter of the first passing lane (a coherent
-                            // wave's rays agree on it closely enough); the child index rides in
-                            // the two low mantissa bits
-                            float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                __builtin_bit_cast(int, near), __builtin_ctzll(b)));
-                            key[j] = (__builtin_bit_cast(uint32_t, e) & ~3u) | (uint32_t)j;
-                            n_pass++;
-                        }
-                    }
-                    cswap(key[0], key[1]); cswap(key[2], key[3]);
-                    cswap(key[0], key[2]); cswap(key[1], key[3]);
-                    cswap(key[1], key[2]);
-                    uint32_t word = (key[0] & 3u) | (key[1] & 3u) << 2 | (key[2] & 3u) << 4 |
-                                    (key[3] & 3u) << 6 | n_pass << 8;
-                    state = lane_set(state, l, word);
-                    if (l == 0)
-                        lanebits = lb;
-                    expand = false;
-                }
-                uint32_t word = lane_get(state, l);
-                if ((word >> 8) == 0) {
-                    if (l == tv.top)
-                        break;
-                    l++;
-                    g >>= 2;
-                    continue;
-                }
-                int j = (int)(word & 3u);
-                state = lane_set(state, l, ((word & 0xffu) >> 2) | ((word >> 8) - 1u) << 8);
-                uint32_t node = g * kTreeArity + (uint32_t)j;
-                if (l == 0) {
-                    test_triangle<P>(tris, node, w, lanebits, j);
-                } else {
-                    l--;
-                    g = node;
-                    expand = true;
-                }
-            }
-        } else {
-            for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
-                test_triangle<P>(tris, node, w, 0xffffffffu, 0);
-        }
-
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            RayPair &r = w.r[p];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                uint32_t i = qbase + (2 * p + h) * 64u + lane;
-                v3 o = mk3(h ? r.ox.y : r.ox.x, h ? r.oy.y : r.oy.x, h ? r.oz.y : r.oz.x);
-                v3 d = mk3(h ? r.dx.y : r.dx.x, h ? r.dy.y : r.dy.x, h ? r.dz.y : r.dz.x);
-                float best = h ? r.best.y : r.best.x;
-                int32_t id = h ? r.idy : r.idx;
-                for (int s = 0; s < n_spheres; s++) {       // quadrics come last (Scene.cu:31-37)
-                    float t;
-                    if (sphere_hit(spheres[s], o, d, best, t)) {
-                        best = t;
-                        id = n_tris + s;
-                    }
-                }
-                if (!live[2 * p + h])
-                    continue;
-                if (SHADOW) {
-                    // Scene.cu:225-227: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
-                    // (H3: `lightidx == idx` restated as never true for point lights)
-                    bool blocked = false;
-                    if (scene_ishit(best) && id >= 0) {
-                        Ray sr; sr.o = o; sr.d = d;
-                        v3 hp = id < n_tris ? ray_pos(sr, best)
-                                            : hit_pos_sphere(spheres[id - n_tris], sr, best);
-                        blocked = length(sub(hp, o)) < thr[2 * p + h];
-                    }
-                    sh_thr[i] = blocked ? 1.0f : 0.0f;
-                } else {
-                    out_t[i] = best;
-                    out_id[i] = id;
-                }
-            }
-        }
+        if (CULL && n_heavy && fb.flag_r[chunk])
+            continue;                            // went out with the heavy ones
+        process_chunk<P, CULL, SHADOW, false>(A, chunk, lane, wib, nullptr, nullptr);
     }
 }
 
@@ -675,25 +839,33 @@ void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n)
     k_gen<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(v, p0, n);
 }
 
+// Rays per chunk: two packed pairs per lane measured slower than one on every config (a
+// wave visits the union of what its rays need, and the longest chunks set the kernel's
+// length), so the default is one pair = 128 rays; RT_ISECT_PAIRS=2 keeps the other form.
+static bool intersect_wide(const DevView &v) { return v.isect_pairs == 2; }
+uint32_t intersect_rays_per_chunk(const DevView &v, uint32_t) { return intersect_wide(v) ? 256u : 128u; }
+
 // One launch of the closest-hit kernel over `capacity` queue slots at most.  Shadow form:
-// sh_thr != nullptr, the queue is n_slabs slabs of `stride` slots (see k_intersect).
+// sh_thr != nullptr, the queue is n_slabs slabs of `stride` slots (see process_chunk).
+// work / work_next: this launch's and the next launch's pair of dispenser counters.
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
                       uint32_t capacity, float *out_t, int32_t *out_id, float *sh_thr,
                       uint32_t stride, uint32_t n_slabs, int max_blocks, uint32_t *work,
-                      uint32_t *work_next)
+                      uint32_t *work_next, const ChunkFeedback *fb)
 {
-    // 4 rays per lane when that still leaves every SIMD several waves, else 2
-    const bool wide = v.isect_pairs ? v.isect_pairs == 2 : capacity >= (1u << 20);
+    const bool wide = intersect_wide(v);
     const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
     const uint32_t rays_per_block = kBlock * (wide ? 4u : 2u);
     unsigned long long gl = ((unsigned long long)capacity + rays_per_block - 1) / rays_per_block;
     if (sh_thr) gl *= n_slabs;
     uint32_t g = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(gl, 1ull),
                                                         (unsigned long long)max_blocks);
+    ChunkFeedback f{};
+    if (fb && dynamic) f = *fb;
 #define RT_LAUNCH_INTERSECT(P, CULL, SH)                                                        \
     k_intersect<P, CULL, SH><<<g, kBlock, 0, s>>>(v.tree, v.tris, v.spheres, v.n_tris,          \
                                                   v.n_spheres, q, count, out_t, out_id, sh_thr, \
-                                                  stride, n_slabs, work, work_next, dynamic)
+                                                  stride, n_slabs, work, work_next, dynamic, f)
     if (sh_thr) {
         if (v.cull) { if (wide) RT_LAUNCH_INTERSECT(2, true, true); else RT_LAUNCH_INTERSECT(1, true, true); }
         else        { if (wide) RT_LAUNCH_INTERSECT(2, false, true); else RT_LAUNCH_INTERSECT(1, false, true); }

@@ -1,7 +1,7 @@
 """Seeded synthetic scenes for the five BASELINE.json configs.
 
-The real Stanford meshes are not in the container, so C3/C4 use seeded displaced-sphere
-meshes with the SAME triangle counts (69 451 / 871 414) and C5 a 10 000 000-triangle
+The real Stanford meshes are not in the container, so C3/C4 use seeded displaced geodesic
+spheres with the SAME triangle counts (69 451 / 871 414) and C5 a 10 000 000-triangle
 height field.  Meshes are built at the scale hazard H1 demands (typical 2*area >> 0.01,
 because Triangle::hit uses absolute tolerances, Model/Model.cu:99,113).  All surfaces are
 Lambertian, albedo 0.7.  Every generator is deterministic (numpy default_rng(seed)).
@@ -116,6 +116,43 @@ def blob_mesh(n_lon, n_lat, radius, seed, bump=0.18):
     return pos.astype(np.float32), nrm.astype(np.float32)
 
 
+def geodesic_blob_mesh(f, radius, seed, bump=0.18):
+    """Displaced geodesic sphere: every face of an icosahedron split into f*f triangles
+    (20 f^2 in all), vertices pushed out to the sphere and displaced by seeded low-frequency
+    bumps.  Triangle sizes are uniform over the whole surface, like a scanned mesh's (a
+    lat-long sphere crowds thousands of slivers into its two poles)."""
+    rng = np.random.default_rng(seed)
+    k = 6
+    axes = rng.normal(size=(k, 3))
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    freq = rng.integers(2, 7, size=k).astype(np.float64)
+    phase = rng.uniform(0, 2 * np.pi, size=k)
+    amp = rng.uniform(0.3, 1.0, size=k)
+    amp *= bump / amp.sum()
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    V = np.array([(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t),
+                  (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)], np.float64)
+    F = np.array([(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4),
+                  (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8),
+                  (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)])
+    # barycentric lattice of one face: upward and downward sub-triangles
+    ii, jj = np.meshgrid(np.arange(f), np.arange(f), indexing="ij")
+    up = ii + jj < f
+    dn = ii + jj < f - 1
+    def corners(i, j):
+        return np.stack([f - i - j, i, j], -1) / float(f)
+    tri_up = np.stack([corners(ii[up], jj[up]), corners(ii[up] + 1, jj[up]), corners(ii[up], jj[up] + 1)], 1)
+    tri_dn = np.stack([corners(ii[dn] + 1, jj[dn]), corners(ii[dn] + 1, jj[dn] + 1), corners(ii[dn], jj[dn] + 1)], 1)
+    bary = np.concatenate([tri_up, tri_dn])                      # [f*f, 3 corners, 3 weights]
+    P = np.einsum("tcw,fwx->ftcx", bary, V[F]).reshape(-1, 3, 3)  # [20 f^2, 3, 3]
+    D = P / np.linalg.norm(P, axis=-1, keepdims=True)
+    r = np.ones(D.shape[:-1])
+    for i in range(k):
+        r += amp[i] * np.sin(freq[i] * (D @ axes[i]) * np.pi + phase[i])
+    pos = D * (r * radius)[..., None]
+    return pos.astype(np.float32), D.astype(np.float32)
+
+
 def grid_mesh(nx, nz, x0, x1, z0, z1, y, seed=None, amp=0.0):
     """Height field over [x0,x1] x [z0,z1]: 2 * nx * nz triangles, central-difference normals."""
     xs = np.linspace(x0, x1, nx + 1)
@@ -178,8 +215,12 @@ def c2(width=1920, height=1080):
                   "Cornell box (36 tris), 2 point lights, 1920x1080, 16 spp")
 
 
-def _blob_scene(n_lon, n_lat, radius, ground, backdrop, seed, lights):
-    pos, nrm = blob_mesh(n_lon, n_lat, radius, seed)
+def _blob_scene(mesh, radius, ground, backdrop, seed, lights):
+    """mesh = ("geodesic", f) or ("latlong", n_lon, n_lat)."""
+    if mesh[0] == "geodesic":
+        pos, nrm = geodesic_blob_mesh(mesh[1], radius, seed)
+    else:
+        pos, nrm = blob_mesh(mesh[1], mesh[2], radius, seed)
     z = -4.2 * radius
     b = SceneBuilder()
     if backdrop:
@@ -203,27 +244,30 @@ def _blob_scene(n_lon, n_lat, radius, ground, backdrop, seed, lights):
     return b.build()
 
 
-def c3(width=1920, height=1080, lon=180, lat=180, ground=(75, 31)):
-    """'Stanford bunny' stand-in: 2*180*180 + 2*75*31 + 1 = 69 451 triangles, 3 lights."""
+def c3(width=1920, height=1080, f=58, ground=(35, 31), lon=None, lat=None):
+    """'Stanford bunny' stand-in: 20*58*58 + 2*35*31 + 1 = 69 451 triangles, 3 lights.
+    (lon, lat given: the lat-long sphere of the decimated test cases and fixtures.)"""
     R = 125.0
     k = R * R * 16.0
     lights = [((-3.0 * R, 3.0 * R, -1.5 * R), (3.0 * k, 2.6 * k, 2.2 * k)),
               ((3.5 * R, 2.0 * R, -2.0 * R), (1.2 * k, 1.5 * k, 2.0 * k)),
               ((0.0, 4.0 * R, -6.0 * R), (1.5 * k, 1.5 * k, 1.5 * k))]
-    s = _blob_scene(lon, lat, R, ground, True, 20240603, lights)
+    mesh = ("latlong", lon, lat) if lon else ("geodesic", f)
+    s = _blob_scene(mesh, R, ground, True, 20240603, lights)
     cam = CameraArgs.for_image(width, height, near=0.6)
     return Config("c3", s, cam, width, height, 64,
                   f"displaced-sphere 'bunny' ({s.n_tris} tris), 3 point lights, 1920x1080, 64 spp")
 
 
-def c4(width=3840, height=2160, lon=660, lat=660, ground=(107, 1)):
-    """'Stanford dragon' stand-in: 2*660*660 + 2*107*1 = 871 414 triangles, C3's 3 lights."""
+def c4(width=3840, height=2160, f=205, ground=(377, 41), lon=None, lat=None):
+    """'Stanford dragon' stand-in: 20*205*205 + 2*377*41 = 871 414 triangles, C3's 3 lights."""
     R = 450.0
     k = R * R * 16.0
     lights = [((-3.0 * R, 3.0 * R, -1.5 * R), (3.0 * k, 2.6 * k, 2.2 * k)),
               ((3.5 * R, 2.0 * R, -2.0 * R), (1.2 * k, 1.5 * k, 2.0 * k)),
               ((0.0, 4.0 * R, -6.0 * R), (1.5 * k, 1.5 * k, 1.5 * k))]
-    s = _blob_scene(lon, lat, R, ground, False, 20240604, lights)
+    mesh = ("latlong", lon, lat) if lon else ("geodesic", f)
+    s = _blob_scene(mesh, R, ground, False, 20240604, lights)
     cam = CameraArgs.for_image(width, height, near=0.6)
     return Config("c4", s, cam, width, height, 256,
                   f"displaced-sphere 'dragon' ({s.n_tris} tris), 3 point lights, 3840x2160, 256 spp")

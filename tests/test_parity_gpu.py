@@ -157,6 +157,31 @@ def test_culling_render_equals_scan(gpu_ctx_factory):
     check_images(out[0], ref)
 
 
+def test_heavy_chunk_feedback_and_cooperative_form(gpu_ctx_factory):
+    """From the third progressive sample on, chunks the previous sample found heavy are
+    handed out first and shared by the four waves of a block (merge by 64-bit min in LDS).
+    Six samples of a deep-tree scene must still match the oracle bit for bit in id / t and
+    the plain scan in every bit of the image."""
+    cfg = scenes.c3(256, 144, f=12, ground=(10, 6))
+    ctx = gpu_ctx_factory(256, 144)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    out = []
+    for cull in (1, 0):
+        ctx.set_culling(cull)
+        ctx.reset()
+        ctx.reset_stats()
+        for _ in range(3):
+            ctx.render(2, 0)
+        out.append(ctx.read_framebuffer())
+        st = ctx.stats()
+    ctx.set_culling(1)
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    ref = orc.render(cfg.scene, cfg.camera, 256, 144, spp=6, max_depth=0)
+    check_images(out[0], ref, st)
+
+
 @pytest.mark.parametrize("depth,spp", [(0, 1), (0, 3), (12, 2)])
 def test_c1_sphere(gpu_ctx_factory, depth, spp):
     cfg = scenes.c1(160, 120)

@@ -85,11 +85,24 @@ __global__ __launch_bounds__(kBlock) void k_gen(DevView v, uint32_t p0, uint32_t
 // A single wave retires a heavy chunk at about a microsecond per node group, and a kernel
 // cannot end before its longest chunk does.
 
+#ifdef RT_TRAV_STATS
+struct ChunkLog { unsigned long long t0, t1; unsigned cost, coop; };
+__device__ ChunkLog g_log[1 << 17];
+__device__ unsigned g_log_on;
+extern "C" void rt_debug_log(void *out, unsigned on, unsigned n)
+{
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_log), sizeof(ChunkLog) * n);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_log_on), &on, sizeof(on));
+}
+#endif
+
 template <int P>
 struct WaveRays {
     RayPair r[P];
 };
 
+constexpr unsigned long long kHeavyFactor = 8;   // heavy = this many times the mean chunk cost (4 and 16 measured slower)
 constexpr int kSplitLevel = 2;       // cooperative chunks: subtrees of 4^(kSplitLevel+1) triangles
 
 __device__ __forceinline__ unsigned long long pack_hit(float t, int32_t id)
@@ -178,6 +191,9 @@ __device__ __forceinline__ void process_chunk(const IsectArgs &A, uint32_t chunk
     const uint32_t qbase = slab * A.stride + base;                         // queue position
     const RayQueue &q = A.q;
     uint32_t cost = 0;                           // node groups expanded + triangles tested
+#ifdef RT_TRAV_STATS
+    unsigned long long tlog0 = (unsigned long long)wall_clock64();
+#endif
     WaveRays<P> w;
     float thr[R];
     bool live[R];
@@ -377,6 +393,10 @@ __device__ __forceinline__ void process_chunk(const IsectArgs &A, uint32_t chunk
         if (wib != 0)
             return;                              // one wave writes the chunk's results
     }
+#ifdef RT_TRAV_STATS
+    if (lane == 0 && g_log_on == (SHADOW ? 2u : 1u) && chunk < (1u << 17))
+        g_log[chunk] = ChunkLog{tlog0, (unsigned long long)wall_clock64(), cost, COOP ? 1u : 0u};
+#endif
     if (A.feedback && lane == 0) {
         const bool heavy = cost >= A.heavy_cost;
         A.fb.flag_w[chunk] = heavy ? 1 : 0;
@@ -465,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(TreeView tv, const TriRec 
         n_heavy = *fb.n_heavy_r;
         unsigned long long total = *fb.total_r;
         if (total)
-            A.heavy_cost = (uint32_t)std::max<unsigned long long>(4ull * total / std::max(n_chunks, 1u), 48ull);
+            A.heavy_cost = (uint32_t)std::max<unsigned long long>(kHeavyFactor * total / std::max(n_chunks, 1u), 96ull);
     }
 
     // phase 1: the previous sample's heavy chunks, one per block

@@ -63,7 +63,7 @@ struct rt_context {
     std::vector<uint32_t> h_pixmap;
     std::vector<Lane> lanes;             // streams/events live as long as the context
     int n_lanes = 1;                     // lanes in use for the current partition
-    int lanes_wanted = 4;
+    int lanes_wanted = 2;                // 2 measured best (C3, C4); more only add launches
 
     bool have_scene = false, have_cam = false;
     int n_lights = 0;

@@ -78,8 +78,8 @@ typedef struct rt_stats {
     uint64_t primary_rays;   /* camera rays                                         */
     uint64_t shadow_rays;    /* shadow rays actually cast (Scene.cu:224-225)        */
     uint64_t bounce_rays;    /* rays of bounces >= 1 whose hit is used              */
-    uint64_t intersect_launches; /* launches of the closest-hit kernel              */
-    double intersect_ms;     /* their summed HIP-event duration (timing mode only)  */
+    uint64_t path_launches;  /* launches of the path kernel (one per sample per stream) */
+    double path_ms;          /* their summed HIP-event duration (timing mode only)  */
     double render_ms;        /* HIP-event duration of whole rt_render calls         */
     uint64_t n_prims;        /* triangles + quadrics of the uploaded scene          */
 } rt_stats;
@@ -166,7 +166,7 @@ int rt_host_bounds(const rt_scene_desc *scene, float *bounds, int32_t *position,
 
 int rt_get_stats(rt_context *ctx, rt_stats *stats);
 int rt_reset_stats(rt_context *ctx);
-/* 1: time every closest-hit launch with HIP events (adds a sync per sample). */
+/* 1: bracket every launch of the path kernel with HIP events on its own stream. */
 int rt_set_timing(rt_context *ctx, int enabled);
 
 const char *rt_last_error(const rt_context *ctx);

@@ -18,35 +18,28 @@ using namespace rt;
 
 namespace {
 
-constexpr uint32_t kMaxBatch = 1u << 21;     // paths in flight per context (all lanes)
 constexpr uint32_t kMinLanePixels = 1u << 16;   // below this a second lane is not worth its launches
-constexpr int kLightsPerPass = 64;           // bits of the per-path shadow mask
 
 thread_local std::string g_err;              // for calls that have no context yet
 
 } // namespace
 
 // A lane renders a fixed, contiguous range of this context's pixels on its own HIP stream
-// with its own queues and counters.  Lanes never touch the same pixel, so they need no
+// with its own dispenser counters.  Lanes never touch the same pixel, so they need no
 // ordering among themselves; their kernels overlap, which is what fills the SIMDs a
 // traversal kernel leaves idle while its few heaviest chunks finish.
 struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     uint32_t lo = 0, hi = 0;             // local pixel range [lo, hi)
-    uint32_t batch = 0;                  // queue capacity (paths)
-    size_t shadow_cap = 0;               // shadow queue capacity (slots)
-    RayQueue rays[2]{}, shadow{};
-    float *hit_t = nullptr;
-    int32_t *hit_id = nullptr;
-    float *sh_thr = nullptr;
-    float *sh_contrib[3] = {nullptr, nullptr, nullptr};
     Ctl *ctl = nullptr;
-    uint32_t isect_seq = 0;              // closest-hit launches so far (dispenser parity)
-    // chunk-order feedback (rt_kernels.h ChunkFeedback), one block per (batch, kind):
-    // kind 0 = primary rays of bounce 0, kind 1 = their shadow rays
-    struct Fb { uint32_t *heavy[2]; uint32_t *n_heavy; unsigned long long *total; uint8_t *flag[2]; size_t chunks; };
-    std::vector<Fb> fb;                  // [batch_index * 2 + kind]
+    uint32_t seq = 0;                    // launches that used this lane's dispensers so far
+    // chunk-order feedback (rt_kernels.h ChunkFeedback): three sets rotating by launch
+    uint32_t *heavy[3] = {nullptr, nullptr, nullptr};
+    uint8_t *flag[3] = {nullptr, nullptr, nullptr};
+    uint32_t *n_heavy = nullptr;         // [3]
+    unsigned long long *total = nullptr; // [3]
+    uint32_t fb_seq = 0;                 // path launches so far (set rotation)
 };
 
 struct rt_context {
@@ -76,7 +69,7 @@ struct rt_context {
 
     // stats
     uint64_t samples = 0, primary = 0, launches = 0, timed_launches = 0;
-    double intersect_ms = 0.0, render_ms = 0.0;
+    double path_ms = 0.0, render_ms = 0.0;
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -123,7 +116,7 @@ void free_all(std::vector<void *> &owner)
     owner.clear();
 }
 
-int alloc_queue(rt_context *c, std::vector<void *> &owner, RayQueue &q, size_t n, bool with_path)
+int alloc_queue(rt_context *c, std::vector<void *> &owner, RayQueue &q, size_t n)
 {
     int rc;
     if ((rc = dalloc(c, owner, q.ox, n))) return rc;
@@ -132,8 +125,6 @@ int alloc_queue(rt_context *c, std::vector<void *> &owner, RayQueue &q, size_t n
     if ((rc = dalloc(c, owner, q.dx, n))) return rc;
     if ((rc = dalloc(c, owner, q.dy, n))) return rc;
     if ((rc = dalloc(c, owner, q.dz, n))) return rc;
-    q.path = nullptr;
-    if (with_path && (rc = dalloc(c, owner, q.path, n))) return rc;
     return RT_OK;
 }
 
@@ -166,71 +157,22 @@ void build_pixmap(rt_context *c)
     c->n_local = (uint32_t)c->h_pixmap.size();
 }
 
-int alloc_feedback(rt_context *c, Lane &L);
-
-int alloc_shadow(rt_context *c)
-{
-    // (re)size every lane's shadow queue for its batch size and the light count
-    for (int k = 0; k < c->n_lanes; k++) {
-        Lane &L = c->lanes[k];
-        size_t need = (size_t)L.batch * (size_t)std::max(1, std::min(c->n_lights, kLightsPerPass));
-        if (need <= L.shadow_cap)
-            continue;
-        // shadow buffers live with the partition allocations; outgrown ones stay until re-partition
-        int rc;
-        if ((rc = alloc_queue(c, c->part_allocs, L.shadow, need, false))) return rc;
-        if ((rc = dalloc(c, c->part_allocs, L.sh_thr, need))) return rc;
-        for (int a = 0; a < 3; a++)
-            if ((rc = dalloc(c, c->part_allocs, L.sh_contrib[a], need))) return rc;
-        L.shadow_cap = need;
-    }
-    // the light count sets the number of shadow chunks: start the feedback afresh
-    for (int k = 0; k < c->n_lanes; k++) {
-        int rc = alloc_feedback(c, c->lanes[k]);
-        if (rc) return rc;
-    }
-    return RT_OK;
-}
-
-// Feedback blocks of a lane, sized for the smallest chunk (128 rays) and the current lights.
+// Feedback sets of a lane: one entry per 128-pixel chunk of its range.
 int alloc_feedback(rt_context *c, Lane &L)
 {
-    L.fb.clear();
-    const size_t span = L.hi - L.lo;
-    if (span == 0) return RT_OK;
-    const size_t n_batches = (span + L.batch - 1) / L.batch;
-    const size_t per_slab = ((size_t)L.batch + 127) / 128;
-    const size_t slabs = (size_t)std::max(1, std::min(c->n_lights, kLightsPerPass));
+    const size_t chunks = ((size_t)(L.hi - L.lo) + kPathChunk - 1) / kPathChunk;
     int rc;
-    for (size_t b = 0; b < n_batches; b++)
-        for (int kind = 0; kind < 2; kind++) {
-            Lane::Fb f{};
-            f.chunks = per_slab * (kind ? slabs : 1);
-            for (int s = 0; s < 2; s++) {
-                if ((rc = dalloc(c, c->part_allocs, f.heavy[s], f.chunks))) return rc;
-                if ((rc = dalloc(c, c->part_allocs, f.flag[s], f.chunks))) return rc;
-                RT_HIP(c, hipMemset(f.flag[s], 0, f.chunks));
-            }
-            if ((rc = dalloc(c, c->part_allocs, f.n_heavy, 2))) return rc;
-            if ((rc = dalloc(c, c->part_allocs, f.total, 2))) return rc;
-            RT_HIP(c, hipMemset(f.n_heavy, 0, 2 * sizeof(uint32_t)));
-            RT_HIP(c, hipMemset(f.total, 0, 2 * sizeof(unsigned long long)));
-            L.fb.push_back(f);
-        }
+    for (int s = 0; s < 3; s++) {
+        if ((rc = dalloc(c, c->part_allocs, L.heavy[s], chunks))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.flag[s], chunks))) return rc;
+        RT_HIP(c, hipMemset(L.flag[s], 0, std::max<size_t>(chunks, 1)));
+    }
+    if ((rc = dalloc(c, c->part_allocs, L.n_heavy, 3))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, L.total, 3))) return rc;
+    RT_HIP(c, hipMemset(L.n_heavy, 0, 3 * sizeof(uint32_t)));
+    RT_HIP(c, hipMemset(L.total, 0, 3 * sizeof(unsigned long long)));
+    L.fb_seq = 0;
     return RT_OK;
-}
-
-// The queue-side fields of a launch's DevView come from the lane.
-DevView lane_view(const rt_context *c, const Lane &L)
-{
-    DevView v = c->v;
-    v.rays[0] = L.rays[0]; v.rays[1] = L.rays[1];
-    v.shadow = L.shadow;
-    v.hit_t = L.hit_t; v.hit_id = L.hit_id;
-    v.sh_thr = L.sh_thr;
-    for (int a = 0; a < 3; a++) v.sh_contrib[a] = L.sh_contrib[a];
-    v.ctl = L.ctl;
-    return v;
 }
 
 int setup_partition(rt_context *c)
@@ -249,12 +191,6 @@ int setup_partition(rt_context *c)
     if ((rc = dalloc(c, c->part_allocs, v.fb, n))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.first_id, n))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.first_t, n))) return rc;
-    for (int k = 0; k < 3; k++) {
-        if ((rc = dalloc(c, c->part_allocs, v.beta[k], n))) return rc;
-        if ((rc = dalloc(c, c->part_allocs, v.res[k], n))) return rc;
-        if ((rc = dalloc(c, c->part_allocs, v.le[k], n))) return rc;
-    }
-    if ((rc = dalloc(c, c->part_allocs, v.bounce_draw, n))) return rc;
 
     // lanes: contiguous pixel ranges cut at 64x64-tile boundaries (4096 local indices)
     int K = (int)std::min<size_t>((size_t)std::max(1, c->lanes_wanted), std::max<size_t>(1, n / kMinLanePixels));
@@ -269,19 +205,11 @@ int setup_partition(rt_context *c)
         };
         L.lo = cut(k);
         L.hi = cut(k + 1);
-        const size_t span = L.hi - L.lo;
-        L.batch = (uint32_t)std::min<size_t>(std::max<size_t>(span, 1), std::max<uint32_t>(kMaxBatch / (uint32_t)K, 1u << 18));
-        L.shadow_cap = 0;
-        L.isect_seq = 0;
-        for (int q = 0; q < 2; q++)
-            if ((rc = alloc_queue(c, c->part_allocs, L.rays[q], L.batch, true))) return rc;
-        if ((rc = dalloc(c, c->part_allocs, L.hit_t, (size_t)L.batch))) return rc;
-        if ((rc = dalloc(c, c->part_allocs, L.hit_id, (size_t)L.batch))) return rc;
+        L.seq = 0;
         if ((rc = dalloc(c, c->part_allocs, L.ctl, 1))) return rc;
         RT_HIP(c, hipMemset(L.ctl, 0, sizeof(Ctl)));
+        if ((rc = alloc_feedback(c, L))) return rc;
     }
-    if ((rc = alloc_shadow(c))) return rc;
-    c->v = lane_view(c, c->lanes[0]);
     return RT_OK;
 }
 
@@ -317,30 +245,34 @@ void resolve_events(rt_context *c)
     for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, c->ev_pool[k], c->ev_pool[k + 1]) == hipSuccess) {
-            c->intersect_ms += ms;
+            c->path_ms += ms;
             c->timed_launches++;
         }
     }
     c->ev_used = 0;
 }
 
-// One closest-hit launch on a lane, optionally bracketed by HIP events on the lane's stream.
-// sh_thr != nullptr: shadow form over n_slabs light slabs of `stride` slots.
-void timed_intersect(rt_context *c, Lane &L, const DevView &v, const RayQueue &q,
-                     const uint32_t *count, uint32_t cap, float *out_t, int32_t *out_id,
-                     float *sh_thr = nullptr, uint32_t stride = 0, uint32_t n_slabs = 1,
-                     const ChunkFeedback *fb = nullptr)
+// One launch of the path kernel on a lane (one progressive sample of its pixel range),
+// optionally bracketed by HIP events on the lane's stream.
+void timed_path(rt_context *c, Lane &L, const DevView &v, int max_depth)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         e0 = next_event(c);
         e1 = next_event(c);
     }
+    // feedback sets rotate by launch: read what the previous launch wrote, write the next
+    // set, zero the one after (nobody touches it during this launch)
+    ChunkFeedback f{};
+    const int r = (int)((L.fb_seq + 2u) % 3u), w = (int)(L.fb_seq % 3u), z = (int)((L.fb_seq + 1u) % 3u);
+    f.heavy_r = L.heavy[r]; f.n_heavy_r = L.n_heavy + r; f.total_r = L.total + r; f.flag_r = L.flag[r];
+    f.heavy_w = L.heavy[w]; f.n_heavy_w = L.n_heavy + w; f.total_w = L.total + w; f.flag_w = L.flag[w];
+    f.n_heavy_z = L.n_heavy + z; f.total_z = L.total + z;
     if (e0) (void)hipEventRecord(e0, L.stream);
-    launch_intersect(L.stream, v, q, count, cap, out_t, out_id, sh_thr, stride, n_slabs,
-                     c->max_blocks, L.ctl->work[L.isect_seq & 1u],
-                     L.ctl->work[(L.isect_seq + 1u) & 1u], fb);
-    L.isect_seq++;
+    launch_path(L.stream, v, L.lo, L.hi - L.lo, max_depth, c->max_blocks, L.ctl,
+                L.ctl->work[L.seq & 1u], L.ctl->work[(L.seq + 1u) & 1u], &f);
+    L.seq++;
+    L.fb_seq++;
     if (e1) (void)hipEventRecord(e1, L.stream);
     c->launches++;
 }
@@ -380,7 +312,6 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     c->v.width = width;
     c->v.height = height;
     c->v.cull = 1;
-    if (const char *e = std::getenv("RT_ISECT_PAIRS")) c->v.isect_pairs = std::atoi(e);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_r0);
@@ -481,7 +412,6 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     update_extent(c);
     c->n_lights = v.n_lights;
     c->n_prims = (uint64_t)hs.tris.size() + hs.spheres.size();
-    if ((rc = alloc_shadow(c))) return rc;
     c->have_scene = true;
     return RT_OK;
 }
@@ -538,56 +468,19 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
         return fail(c, RT_ERR_STATE, "rt_render needs rt_upload_scene and rt_set_camera first");
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
-    const int L = c->n_lights;
-    const int n_pass = std::max(1, (L + kLightsPerPass - 1) / kLightsPerPass);
-    const bool use_fb = c->v.cull && c->v.tree.top >= 3;      // same test as the launcher's `dynamic`
     hipStream_t s0 = c->stream;
     RT_HIP(c, hipEventRecord(c->ev_r0, s0));                 // fork: lanes start after the main stream
     for (int k = 0; k < c->n_lanes; k++)
         RT_HIP(c, hipStreamWaitEvent(c->lanes[k].stream, c->ev_r0, 0));
     for (int smp = 0; smp < n_samples; smp++) {
         c->cnt++;
+        DevView v = c->v;
+        v.cnt = c->cnt;
         for (int k = 0; k < c->n_lanes; k++) {
             Lane &ln = c->lanes[k];
-            hipStream_t s = ln.stream;
-            DevView v = lane_view(c, ln);
-            v.cnt = c->cnt;
-            size_t bi = 0;
-            for (uint32_t p0 = ln.lo; p0 < ln.hi; p0 += ln.batch, bi++) {
-                const uint32_t n = std::min(ln.batch, ln.hi - p0);
-                // heavy-first chunk order from the previous sample (bounce 0, single light pass)
-                auto feedback = [&](int kind, ChunkFeedback &f) -> const ChunkFeedback * {
-                    if (n_pass != 1 || bi * 2 + kind >= ln.fb.size()) return nullptr;
-                    const Lane::Fb &b = ln.fb[bi * 2 + kind];
-                    const int r = c->cnt & 1, w = r ^ 1;
-                    f.heavy_r = b.heavy[r]; f.n_heavy_r = b.n_heavy + r; f.total_r = b.total + r; f.flag_r = b.flag[r];
-                    f.heavy_w = b.heavy[w]; f.n_heavy_w = b.n_heavy + w; f.total_w = b.total + w; f.flag_w = b.flag[w];
-                    (void)hipMemsetAsync(b.n_heavy + w, 0, sizeof(uint32_t), s);
-                    (void)hipMemsetAsync(b.total + w, 0, sizeof(unsigned long long), s);
-                    return &f;
-                };
-                ChunkFeedback f0{}, f1{};
-                launch_ctl_begin(s, v.ctl, n);
-                launch_gen(s, v, p0, n);
-                int cur = 0;
-                for (int bounce = 0; bounce <= max_depth; bounce++) {
-                    timed_intersect(c, ln, v, v.rays[cur], &v.ctl->n_cur, n, v.hit_t, v.hit_id, nullptr, 0,
-                                    1, bounce == 0 && use_fb ? feedback(0, f0) : nullptr);
-                    for (int pass = 0; pass < n_pass; pass++) {
-                        const int l0 = pass * kLightsPerPass;
-                        const int nl = std::max(0, std::min(kLightsPerPass, L - l0));
-                        launch_shade(s, v, n, cur, bounce, l0, nl, L, ln.batch, c->max_blocks);
-                        if (nl > 0)     // shadow rays of this pass: nl light slabs of `batch` slots
-                            timed_intersect(c, ln, v, v.shadow, &v.ctl->n_cur, n, nullptr, nullptr,
-                                            v.sh_thr, ln.batch, (uint32_t)nl,
-                                            bounce == 0 && use_fb ? feedback(1, f1) : nullptr);
-                        launch_finish(s, v, n, cur, bounce, max_depth, l0, nl, pass == n_pass - 1,
-                                      ln.batch, c->max_blocks);
-                    }
-                    launch_ctl_next_bounce(s, v.ctl);
-                    cur ^= 1;
-                }
-                c->primary += n;
+            if (ln.hi > ln.lo) {
+                timed_path(c, ln, v, max_depth);
+                c->primary += ln.hi - ln.lo;
             }
         }
         c->samples += c->n_local;
@@ -690,28 +583,24 @@ extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float 
     RayQueue q{};
     float *d_org = nullptr, *d_dir = nullptr, *d_t = nullptr;
     int32_t *d_id = nullptr, *d_hit = nullptr;
-    uint32_t *d_count = nullptr;
-    int rc = alloc_queue(c, tmp, q, (size_t)n, false);
+    int rc = alloc_queue(c, tmp, q, (size_t)n);
     if (!rc) rc = dalloc(c, tmp, d_org, (size_t)n * 3);
     if (!rc) rc = dalloc(c, tmp, d_dir, (size_t)n * 3);
     if (!rc) rc = dalloc(c, tmp, d_t, (size_t)n);
     if (!rc) rc = dalloc(c, tmp, d_id, (size_t)n);
     if (!rc) rc = dalloc(c, tmp, d_hit, (size_t)n);
-    if (!rc) rc = dalloc(c, tmp, d_count, 1);
     hipError_t e = hipSuccess;
     if (!rc) {
         uint32_t un = (uint32_t)n;
         hipStream_t s = c->stream;
         e = hipMemcpyAsync(d_org, org, (size_t)n * 12, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync(d_dir, dir, (size_t)n * 12, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_count, &un, 4, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
             launch_prepare_rays(s, q, d_org, d_dir, un);
             Lane &L0 = c->lanes[0];
-            launch_intersect(s, c->v, q, d_count, un, d_t, d_id, nullptr, 0, 1, c->max_blocks,
-                             L0.ctl->work[L0.isect_seq & 1u], L0.ctl->work[(L0.isect_seq + 1u) & 1u],
-                             nullptr);
-            L0.isect_seq++;
+            launch_intersect(s, c->v, q, un, d_t, d_id, c->max_blocks, L0.ctl->work[L0.seq & 1u],
+                             L0.ctl->work[(L0.seq + 1u) & 1u]);
+            L0.seq++;
             launch_ishit(s, d_t, d_hit, un);
             e = hipStreamSynchronize(s);
         }
@@ -764,8 +653,8 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->primary_rays = c->primary;
     st->shadow_rays = shadow_total;
     st->bounce_rays = bounce_total;
-    st->intersect_launches = c->timing ? c->timed_launches : c->launches;
-    st->intersect_ms = c->intersect_ms;
+    st->path_launches = c->timing ? c->timed_launches : c->launches;
+    st->path_ms = c->path_ms;
     st->render_ms = c->render_ms;
     st->n_prims = c->n_prims;
     return RT_OK;
@@ -778,10 +667,10 @@ extern "C" int rt_reset_stats(rt_context *c)
     RT_HIP(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->n_lanes; k++) {
         RT_HIP(c, hipMemset(c->lanes[k].ctl, 0, sizeof(Ctl)));
-        c->lanes[k].isect_seq = 0;
+        c->lanes[k].seq = 0;
     }
     c->samples = c->primary = c->launches = c->timed_launches = 0;
-    c->intersect_ms = c->render_ms = 0.0;
+    c->path_ms = c->render_ms = 0.0;
     return RT_OK;
 }
 

@@ -402,6 +402,14 @@ __device__ __forceinline__ v3 rec_f(const Hit &h, const ModelRec &M, v3 wo, v3 w
         return mk3(0.0f, 0.0f, 0.0f);
     return lambert_f(local_y(h, wo), local_y(h, wi), h.color, M);
 }
+// The same with the outgoing direction already reduced to its local y component
+// (wo_y = dot(wo, normal)), which is all Lambertian::f reads of it.
+__device__ __forceinline__ v3 rec_f_y(const Hit &h, const ModelRec &M, float wo_y, v3 wi)
+{
+    if (M.mat_type != kMatLambertian)
+        return mk3(0.0f, 0.0f, 0.0f);
+    return lambert_f(wo_y, local_y(h, wi), h.color, M);
+}
 // sampleHemi (Material/material.cu:28-50)
 __device__ __forceinline__ v3 sample_hemi(float sx, float sy)
 {
@@ -429,6 +437,21 @@ __device__ __forceinline__ v3 rec_sample_f(const Hit &h, const ModelRec &M, v3 w
     pdf = 0.0f;
     if (M.mat_type == kMatLambertian) {
         float wo_y = local_y(h, wo);
+        wl = sample_hemi(sx, sy);
+        pdf = wl.y > +0.0f ? wl.y * kInvPi : 0.0f;
+        res = lambert_f(wo_y, wl.y, h.color, M);
+    }
+    wi = local2world(h, wl);
+    return res;
+}
+
+__device__ __forceinline__ v3 rec_sample_f_y(const Hit &h, const ModelRec &M, float wo_y, v3 &wi,
+                                             float &pdf, float sx, float sy)
+{
+    v3 res = mk3(0.0f, 0.0f, 0.0f);
+    v3 wl = mk3(0.0f, 0.0f, 0.0f);
+    pdf = 0.0f;
+    if (M.mat_type == kMatLambertian) {
         wl = sample_hemi(sx, sy);
         pdf = wl.y > +0.0f ? wl.y * kInvPi : 0.0f;
         res = lambert_f(wo_y, wl.y, h.color, M);

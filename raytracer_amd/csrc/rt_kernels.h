@@ -7,23 +7,18 @@
 
 namespace rt {
 
-// Queue lengths and ray totals, resident in device memory so that a whole
-// sample is enqueued without reading anything back.
+// Per-lane control block, resident in device memory.
 struct Ctl {
-    uint32_t n_cur;        // active paths of the current bounce
-    uint32_t n_next;       // survivors pushed for the next bounce
-    uint32_t pad[2];
-    // Chunk dispensers of the closest-hit kernel: [0] waves draw ordinary chunks, [1] blocks
-    // draw the heavy ones.  Launch k uses pair k & 1 and zeroes the other for launch k + 1.
+    // Chunk dispensers: [0] waves draw ordinary chunks, [1] blocks draw the heavy ones.
+    // Launch k uses pair k & 1 and zeroes the other for launch k + 1.
     uint32_t work[2][2];
     unsigned long long shadow_total;   // shadow rays cast since rt_reset_stats
     unsigned long long bounce_total;   // bounce (>= 1) rays traced since rt_reset_stats
 };
 
-// Struct-of-arrays ray queue: lane i of a wave reads element base + i of each array.
+// Struct-of-arrays ray queue of rt_scene_hit: lane i of a wave reads element base + i.
 struct RayQueue {
     float *ox, *oy, *oz, *dx, *dy, *dz;
-    uint32_t *path;        // local path (pixel) index; unused for shadow queues
 };
 
 // Implicit 4-ary box tree over the triangle records (rt_math.h NodeGroup; built by
@@ -37,13 +32,13 @@ struct TreeView {
     float extent;          // rays whose origin leaves [-extent, extent]^3 are never culled
 };
 
-// Chunk-order feedback of the closest-hit kernel (deep trees only).  A chunk's cost is
-// stable from one progressive sample to the next (same pixels, same slots), so each
-// launch records which chunks were heavy and the next launch of the same queue hands
-// those out FIRST: the kernel then ends with cheap chunks instead of waiting for a
-// straggler that was dispensed last.  Two sets alternate by sample parity: `r` was
-// written by the previous sample, `w` is written now.  Only an ordering hint -- every
-// chunk is still processed exactly once.
+// Chunk-order feedback of the path kernel (deep trees only).  A chunk's cost is stable
+// from one progressive sample to the next (same pixels), so each launch records which
+// chunks were heavy and the next launch hands those out FIRST, one per block
+// (cooperative form): the kernel then ends with cheap chunks instead of waiting for a
+// straggler that was dispensed last.  Three sets rotate by launch number: `r` was
+// written by the previous launch, `w` is written now, `z` is zeroed now for the next
+// launch to write.  Only an ordering hint -- every chunk is processed exactly once.
 struct ChunkFeedback {
     const uint32_t *heavy_r;             // chunk ids that were heavy
     const uint32_t *n_heavy_r;
@@ -53,6 +48,8 @@ struct ChunkFeedback {
     uint32_t *n_heavy_w;
     unsigned long long *total_w;
     uint8_t *flag_w;
+    uint32_t *n_heavy_z;
+    unsigned long long *total_z;
 };
 
 struct DevView {
@@ -65,7 +62,6 @@ struct DevView {
     const TriCold *tri_cold;        // reference traversal order
     TreeView tree;
     int cull;                       // 0: scan every triangle (validation), 1: use the tree
-    int isect_pairs;                // ray pairs per lane in k_intersect: 1, 2, or 0 = by queue size
     const ModelRec *models;
     const SphereRec *spheres;
     const LightRec *lights;
@@ -76,32 +72,20 @@ struct DevView {
     float4 *fb;                     // RGBA32F running mean
     int32_t *first_id;
     float *first_t;
-    // per-sample path state, per local pixel
-    float *beta[3], *res[3], *le[3];
-    uint32_t *bounce_draw;
-    // per queue position (batch-sized)
-    RayQueue rays[2];
-    float *hit_t;
-    int32_t *hit_id;
-    // shadow-ray queue
-    RayQueue shadow;
-    float *sh_thr;                  // in: |o - l| - 0.01 (or -1: empty slot); out: 1 blocked / 0 visible
-    float *sh_contrib[3];
-    Ctl *ctl;
 };
 
-void launch_ctl_begin(hipStream_t s, Ctl *ctl, uint32_t n);
-void launch_ctl_next_bounce(hipStream_t s, Ctl *ctl);
-void launch_gen(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n);
-void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, const uint32_t *count,
-                      uint32_t capacity, float *out_t, int32_t *out_id, float *sh_thr,
-                      uint32_t stride, uint32_t n_slabs, int max_blocks, uint32_t *work,
-                      uint32_t *work_next, const ChunkFeedback *fb);
-uint32_t intersect_rays_per_chunk(const DevView &v, uint32_t capacity);
-void launch_shade(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce, int l0,
-                  int nl, int n_lights_total, uint32_t stride, int max_blocks);
-void launch_finish(hipStream_t s, const DevView &v, uint32_t capacity, int cur, int bounce,
-                   int max_depth, int l0, int nl, int last_pass, uint32_t stride, int max_blocks);
+// One progressive sample of local pixels [p0, p0 + n): the whole path of every pixel
+// (kernel.cu:50-79 -> pathTracer) in ONE launch.  work / work_next: this launch's and the
+// next launch's pair of dispenser counters; fb may be null (no feedback).
+void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
+                 int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
+                 const ChunkFeedback *fb);
+constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (two per lane)
+
+// Scene::hit on a queue of caller rays (rt_scene_hit).
+void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,
+                      float *out_t, int32_t *out_id, int max_blocks, uint32_t *work,
+                      uint32_t *work_next);
 void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,
                           const int32_t *first_id, const float *first_t, float4 *rgba,
                           int32_t *prim, float *t);

@@ -10,16 +10,24 @@ scene resident in HBM.  With N > 1 the frame is tile-partitioned over the ranks 
 tiles, round-robin; scene replicated) and the step ends with the RCCL gather of the
 partition framebuffers -- total work is fixed, so scaling is "strong".
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_intersect, the
-closest hit): algorithmic bytes per launch / its mean HIP-event duration, against the
-8 TB/s HBM peak.  Algorithmic bytes of the culled kernel ("Measurement"):
-32 B per ray (24 B ray in, 8 B (t, id) out) + one pass over the scene records per
-launch (64 B triangle record + 32 B of box tree per triangle).  The figure SURVEY 8(d)
-defined for a plain scan (every ray streams every triangle, one fetch shared by 256
-rays) is reported next to it as `scan_equivalent`: it is what a scan would have had to
-move to produce the same result in the same time.  `cpu_baseline` is the CPU oracle (a
-port of the reference's per-pixel code) timed on this box's host cores on a bounded
-crop of the same workload.
+The default workload is C3 (BASELINE.json configs[2]): the largest single-GPU 1080p
+configuration and the one the metric's "primary+shadow" wording describes (69 451
+triangles, 3 lights with shadow rays, 64 spp).  `--config c2` runs configs[1] (Cornell
+box, 36 triangles, 16 spp), whose whole step is a few milliseconds.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, k_path (the whole
+path of a pixel-sample in one launch: ray generation, closest hit, shadow rays, shading,
+accumulate): algorithmic bytes per launch / its mean HIP-event duration (events on the
+stream the kernel runs on), against the 8 TB/s HBM peak.  Unit = one pixel-sample.
+Algorithmic bytes per unit ("Measurement"): 52 B = framebuffer texel read +
+write (32), RNG counter read + write (8), pixel-map entry (4), id + t buffers (8); plus
+one pass over the scene records per launch (64 B triangle record + 32 B of box tree per
+triangle, 132 B per sphere).  Rays, hits and shadow rays never touch HBM.  The figure
+SURVEY 8(d) defined for a plain scan (every ray streams every triangle, one fetch shared
+by 256 rays) is reported next to it as `scan_equivalent`: it is what a scan would have
+had to move to produce the same result in the same time.  `cpu_baseline` is the CPU
+oracle (a port of the reference's per-pixel code) timed on this box's host cores on a
+bounded crop of the same workload.
 """
 import argparse
 import ctypes as C
@@ -37,7 +45,8 @@ TRI_BYTES = 36.0             # 9 floats of positions per triangle (
 TRI_REC_BYTES = 64.0 + 32.0  # culled kernel: TriRec + its share of the box tree (24 B * 4/3)
 SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
-RAY_IO_BYTES = 32.0          # 24 B ray in + 8 B (t, id) out per ray
+RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out per ray
+PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
 
 
 def parse():
@@ -45,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--spp", type=int, default=0, help="samples per step (default: the config's)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -56,7 +65,7 @@ def parse():
 
 def measured_traffic(cfg_name, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
+    (profiles/r01_traffic_k_path.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
     None if there is no profile for this workload."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -161,13 +170,14 @@ def main():
     if rank == 0:
         sc = cfg.scene
         n_tri, n_sph = sc.n_tris, sc.n_quads
-        # dominant kernel: closest hit.  Units of one launch = rays; per-unit figure below.
+        # dominant (only) kernel of the step: k_path.  Unit of a launch = pixel-samples.
         rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
-        launches = max(1, st.intersect_launches)
-        k_ms = st.intersect_ms / launches
+        launches = max(1, st.path_launches)
+        k_ms = st.path_ms / launches
+        units_per_launch = float(st.samples) / launches
         rays_per_launch = rays_k / launches
-        # culled kernel: ray I/O + the scene records once per launch
-        bytes_per_launch = RAY_IO_BYTES * rays_per_launch + n_tri * TRI_REC_BYTES + n_sph * SPH_BYTES
+        bytes_per_launch = (PIXEL_SAMPLE_BYTES * units_per_launch + n_tri * TRI_REC_BYTES
+                            + n_sph * SPH_BYTES)
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # what a scan would have had to move for the same result in the same time
         scan_per_ray = (n_tri * TRI_BYTES + n_sph * SPH_BYTES) / RAYS_PER_FETCH + RAY_IO_BYTES
@@ -193,19 +203,21 @@ def main():
                        "rays_per_step": rays_total / a.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(cfg.name, "k_intersect"),
-                         "kernel": "k_intersect", "avg_launch_ms": k_ms,
+                         "traffic": measured_traffic(cfg.name, "k_path"),
+                         "kernel": "k_path", "avg_launch_ms": k_ms,
                          "launches_timed": int(launches),
                          "bytes_per_launch": bytes_per_launch,
+                         "pixel_samples_per_launch": units_per_launch,
                          "rays_per_launch": rays_per_launch,
-                         "intersect_share_of_step": st.intersect_ms / (st.render_ms or 1.0),
-                         "note": "tree traversal is bound by VALU issue and scalar-load "
-                                 "latency, not HBM (DESIGN.md); HBM fraction reported as asked"},
+                         "concurrent_streams": int(st.streams),
+                         "note": "the path is bound by VALU issue and scalar-load latency of the "
+                                 "tree traversal, not by HBM (DESIGN.md); HBM fraction reported "
+                                 "as asked"},
             "scan_equivalent": {"model": "SURVEY 8(d): every ray streams every primitive, one "
                                          "fetch per 256 rays",
                                 "gbs": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
-                                "pair_tests_per_s": tests / (st.intersect_ms * 1e-3)
-                                if st.intersect_ms else 0.0},
+                                "pair_tests_per_s": tests / (dt / a.steps * 1e-3) / a.steps
+                                if dt else 0.0},
         }
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (512, 288),

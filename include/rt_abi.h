@@ -82,6 +82,7 @@ typedef struct rt_stats {
     double path_ms;          /* their summed HIP-event duration (timing mode only)  */
     double render_ms;        /* HIP-event duration of whole rt_render calls         */
     uint64_t n_prims;        /* triangles + quadrics of the uploaded scene          */
+    uint64_t streams;        /* HIP streams the partition's pixel ranges render on   */
 } rt_stats;
 
 /* Replaces the surface/graph set-up of initCUDA (kernel.cu:193-256): creates the

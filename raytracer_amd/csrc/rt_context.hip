@@ -657,6 +657,7 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->path_ms = c->path_ms;
     st->render_ms = c->render_ms;
     st->n_prims = c->n_prims;
+    st->streams = (uint64_t)c->n_lanes;
     return RT_OK;
 }
 

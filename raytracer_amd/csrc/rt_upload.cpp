@@ -6,6 +6,7 @@
 #include "rt_upload.h"
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -146,17 +147,6 @@ Box leaf_box(const TriRec &T)
 
 inline bool box_dead(const Box &b) { return b.lo[0] > b.hi[0]; }
 
-inline uint64_t spread21(uint64_t x)
-{
-    x &= 0x1fffffull;
-    x = (x | x << 32) & 0x1f00000000ffffull;
-    x = (x | x << 16) & 0x1f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
-}
-
 template <class F>
 void parallel_for(size_t n, F fn)
 {
@@ -172,7 +162,7 @@ void parallel_for(size_t n, F fn)
     for (auto &t : pool) t.join();
 }
 
-// Order the triangles along a Morton curve of their box centres and stack the
+// Order the triangles by recursive rank partition of their box centres and stack the
 // implicit 4-ary box tree on top.  `tris` arrives in reference traversal order.
 void build_tree(HostScene &hs)
 {
@@ -206,21 +196,65 @@ void build_tree(HostScene &hs)
     // exact line, and ray origins are culled only inside [-E, E]^3, E = kCullExtent * extent
     const double slack = (double)hs.geom_extent * kCullExtent * (1.0 / 524288.0);
 
-    std::vector<std::pair<uint64_t, uint32_t>> key(n);
+    // Device order = the leaf order of the implicit tree.  A group of level l has four
+    // children of 4^l consecutive positions each, so the order is fixed by a recursive
+    // partition by RANK: the triangles of a node are cut into its children's position
+    // ranges with nth_element along the longest axis of their centres (first in two at
+    // the middle child boundary, then each half again along its own longest axis).
+    // Compared with a space-filling-curve order this keeps sibling boxes disjoint in the
+    // cut axis at every level, which is what prunes the traversal.
+    std::vector<float> ctr(3 * n);
     parallel_for(n, [&](size_t g) {
-        uint64_t kx = 0;
-        if (!box_dead(lb[g]) && std::isfinite(lb[g].lo[0])) {
-            uint64_t q[3];
-            for (int i = 0; i < 3; i++) {
-                double w = hi[i] - lo[i];
-                double u = w > 0.0 ? (0.5 * (lb[g].lo[i] + lb[g].hi[i]) - lo[i]) / w : 0.0;
-                q[i] = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097152.0));
-            }
-            kx = spread21(q[0]) | spread21(q[1]) << 1 | spread21(q[2]) << 2;
+        const bool ok = !box_dead(lb[g]) && std::isfinite(lb[g].lo[0]) && std::isfinite(lb[g].hi[0]);
+        for (int i = 0; i < 3; i++) {
+            double c = ok ? 0.5 * (lb[g].lo[i] + lb[g].hi[i]) : 0.0;
+            ctr[3 * g + i] = std::isfinite(c) ? (float)c : 0.0f;
         }
-        key[g] = {kx, (uint32_t)g};
     });
-    std::sort(key.begin(), key.end());
+    std::vector<uint32_t> order(n);
+    for (size_t g = 0; g < n; g++) order[g] = (uint32_t)g;
+    int levels = 0;                                  // children of the top group cover 4^levels positions
+    for (size_t cap = kTreeArity; cap < n; cap *= kTreeArity) levels++;
+    auto cut = [&](size_t lo, size_t mid, size_t hi) {
+        // order[lo, hi) -> the `mid - lo` smallest along the longest axis of the centres first
+        if (mid <= lo || mid >= hi) return;
+        float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+        for (size_t k = lo; k < hi; k++)
+            for (int i = 0; i < 3; i++) {
+                float c = ctr[3 * (size_t)order[k] + i];
+                mn[i] = std::min(mn[i], c);
+                mx[i] = std::max(mx[i], c);
+            }
+        int ax = 0;
+        if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+        if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+        std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
+                         [&](uint32_t x, uint32_t y) {
+                             float cx = ctr[3 * (size_t)x + ax], cy = ctr[3 * (size_t)y + ax];
+                             return cx < cy || (cx == cy && x < y);
+                         });
+    };
+    std::function<void(size_t, size_t, int, int)> part = [&](size_t lo, size_t hi, int l, int depth) {
+        // node whose four children cover 4^l positions each, holding order[lo, hi)
+        if (l <= 0 || hi - lo <= 1) return;
+        size_t c = 1;
+        for (int k = 0; k < l; k++) c *= kTreeArity;
+        const size_t m2 = std::min(hi, lo + 2 * c);
+        cut(lo, m2, hi);
+        cut(lo, std::min(m2, lo + c), m2);
+        cut(m2, std::min(hi, lo + 3 * c), hi);
+        std::vector<std::thread> pool;
+        for (int k = 0; k < kTreeArity; k++) {
+            const size_t a = std::min(hi, lo + (size_t)k * c), b = std::min(hi, a + c);
+            if (b <= a) continue;
+            if (depth < 2 && b - a > 65536)
+                pool.emplace_back([&part, a, b, l, depth]() { part(a, b, l - 1, depth + 1); });
+            else
+                part(a, b, l - 1, depth + 1);
+        }
+        for (auto &t : pool) t.join();
+    };
+    part(0, n, levels, 0);
 
     const size_t n_pad = std::max<size_t>(kTreeArity, (n + kTreeArity - 1) / kTreeArity * kTreeArity);
     std::vector<TriRec> sorted(n_pad);
@@ -228,7 +262,7 @@ void build_tree(HostScene &hs)
     hs.pos_of.assign(n, 0u);
     std::vector<Box> level(n_pad, kDeadBox);
     parallel_for(n, [&](size_t pos) {
-        uint32_t g = key[pos].second;
+        uint32_t g = order[pos];
         sorted[pos] = hs.tris[g];
         hs.pos_of[g] = (uint32_t)pos;
         Box b = lb[g];

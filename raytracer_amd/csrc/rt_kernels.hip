@@ -49,6 +49,23 @@ __device__ __forceinline__ bool scene_ishit(float t) { return t > 0.001f && t < 
 // A single wave retires a heavy chunk at about a microsecond per node group, and a kernel
 // cannot end before its longest chunk does.
 
+// Wave-uniform, read-only scene records are read through the constant address space: that
+// pins them to the scalar data path (s_load into SGPRs) whatever the compiler can or cannot
+// prove about stores elsewhere in the kernel.  (Without it the path kernel's traversal
+// fell back to per-lane global_load of the same address -- 24 VGPRs and six TA
+// instructions per node group.)  The scene is written only by rt_upload_scene's copies,
+// which complete before any launch; the scalar cache is invalidated at kernel start.
+template <class T>
+__device__ __forceinline__ T load_uniform(const T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const T __attribute__((address_space(4))) *cptr;
+    return *(cptr)(unsigned long long)p;
+#else
+    return *p;                                   // host pass of the single-source compile
+#endif
+}
+
 constexpr unsigned long long kHeavyFactor = 8;   // heavy = this many times the mean chunk cost (4 and 16 measured slower)
 constexpr int kSplitLevel = 2;       // cooperative chunks: subtrees of 4^(kSplitLevel+1) triangles
 
@@ -68,7 +85,7 @@ struct TravArgs {
 __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, uint32_t node,
                                               RayPair &r, uint32_t lanebits, int j)
 {
-    const TriRec T = tris[node];
+    const TriRec T = load_uniform(&tris[node]);
     bool cx = (lanebits >> (2 * j)) & 1u, cy = (lanebits >> (2 * j + 1)) & 1u;
     if (__ballot(cx | cy)) {
         tri_test_pair(T, r, cx, cy);
@@ -189,7 +206,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
             if (expand) {
                 cost++;
                 if (COOP) merge_in();
-                const NodeGroup G = tv.groups[lane_get(lvloff, l) + g];
+                const NodeGroup G = load_uniform(&tv.groups[lane_get(lvloff, l) + g]);
                 uint32_t key[4], lb = 0, n_pass = 0;
 #pragma unroll
                 for (int j = 0; j < kTreeArity; j++) {
@@ -261,7 +278,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
     }
     // quadrics come last (Scene.cu:31-37), strict < against the triangles' result
     for (int s = 0; s < A.n_spheres; s++) {
-        const SphereRec &S = A.spheres[s];
+        const SphereRec S = load_uniform(&A.spheres[s]);
         float t;
         if (sphere_hit(S, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
             r.best.x = t;
@@ -516,6 +533,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         bool more = false;
         if (__ballot(ishit[0] | ishit[1])) {
             for (j = j + 1; j < L; j++) {
+                const LightRec light = load_uniform(&v.lights[j]);
                 v3 so[2], sd[2];
                 float sb[2], ss[2];
 #pragma unroll
@@ -524,7 +542,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                     so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
                     sb[h] = kInf; ss[h] = -1.0f;
                     if (ishit[h]) {
-                        LightSample s = sample_point_light(S[h].hit(), v.models[S[h].model], S[h].wo_y, v.lights[j]);
+                        LightSample s = sample_point_light(S[h].hit(), v.models[S[h].model], S[h].wo_y, light);
                         cast[h] = s.cast;
                         so[h] = s.sr.o; sd[h] = s.sr.d;
                         // Scene.cu:227 rhs; a negative one (hit within 0.01 of the light)

@@ -323,7 +323,10 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
         delete c;
         return fail(nullptr, RT_ERR_DEVICE, m);
     }
-    c->max_blocks = std::max(1, prop.multiProcessorCount) * 8;
+    // a persistent grid of what is resident at once (two 256-thread blocks per CU at this
+    // kernel's register count); more blocks only queue behind them (measured: 512 best on C3)
+    c->max_blocks = std::max(1, prop.multiProcessorCount) * 2;
+    if (const char *e = std::getenv("RT_MAX_BLOCKS")) c->max_blocks = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("RT_LANES")) c->lanes_wanted = std::max(1, std::min(8, std::atoi(e)));
     int rc = RT_OK;
     c->lanes.resize((size_t)c->lanes_wanted);

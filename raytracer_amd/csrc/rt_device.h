@@ -137,21 +137,22 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct RayPair {
     f2 ox, oy, oz, dx, dy, dz;
-    f2 ix, iy, iz;    // 1 / d per axis (|d| clamped away from 0) for the box tests only
+    f2 ix, iy, iz;    // 1 / d per axis (|d| clamped away from 0) for the box tests only;
+                      // 0 for a ray that is never culled ("wild": origin outside the culling
+                      // extent or not finite): every plane parameter is then 0 and every box passes
+    f2 px, py, pz;    // o * (1 / d), so that a plane parameter is one fma: lo * (1/d) - o * (1/d)
     f2 best;          // running closest t per ray (IntersectRecord::t)
-    f2 bestp;         // best * (1 + 2^-19): conservative side of every pre-test
+    f2 bestp;         // best * kBestInfl: conservative side of every pre-test
     f2 stop;          // shadow rays: a hit with t below this ends the ray (-1: never)
     int idx, idy;     // reference traversal index of the closest primitive, -1 = none
-    bool wildx, wildy;   // origin outside the culling extent (or not finite): never culled
 };
 
-constexpr float kBestInfl = 1.000002f;
+constexpr float kBestInfl = 1.000004f;
 constexpr float kEpsDefl = kEps * 0.999999f;
-constexpr float kTnDefl = 0.999998f;
 
 // 1 / d for the slab test.  A component below 1e-30 in magnitude is replaced by +-1e-30:
 // over the t range of the path (t < 1e6) that moves the ray by less than 1e-24, far
-// inside the slack the boxes carry, and keeps every product finite (no 0 * inf).
+// inside the slack the boxes carry.
 __device__ __forceinline__ float slab_inv(float d)
 {
     float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;
@@ -161,24 +162,28 @@ __device__ __forceinline__ float slab_inv(float d)
 // Conservative slab test of one box against both rays: true = some triangle below the
 // node may still be accepted.  [tn, tf] is the parameter interval of o + t d inside
 // the box; the node is skipped when it is empty, ends behind the origin, or starts
-// beyond the closest hit so far (best, inflated).  The factor on tf covers the
-// rounding of the six products (a few ulp each).  `ex`, `ey` return the entry
+// beyond the closest hit so far: tn > min(tf, best) * (1 + 4e-6).  The relative factor
+// covers the rounding of the comparison's two sides; the ABSOLUTE error of a plane
+// parameter computed as fma(lo, 1/d, -(o * 1/d)) is at most 2^-23 |o| |1/d|, i.e. the
+// plane is misplaced by at most 2^-23 |o| <= 2^-23 E in space, which the boxes' slack of
+// 2^-19 E (rt_upload.cpp) covers sixteen times over.  A NaN (0 * inf, inf - inf) drops
+// out of v_min/v_max, which only widens the interval.  `ex`, `ey` return the entry
 // parameter, which orders the traversal.
 __device__ __forceinline__ void node_test(const RayPair &r, float lx, float ly, float lz, float hx,
                                           float hy, float hz, bool &px, bool &py, float &ex,
                                           float &ey)
 {
-    f2 ax = (lx - r.ox) * r.ix, bx = (hx - r.ox) * r.ix;
-    f2 ay = (ly - r.oy) * r.iy, by = (hy - r.oy) * r.iy;
-    f2 az = (lz - r.oz) * r.iz, bz = (hz - r.oz) * r.iz;
+    f2 ax = __builtin_elementwise_fma(f2{lx, lx}, r.ix, -r.px), bx = __builtin_elementwise_fma(f2{hx, hx}, r.ix, -r.px);
+    f2 ay = __builtin_elementwise_fma(f2{ly, ly}, r.iy, -r.py), by = __builtin_elementwise_fma(f2{hy, hy}, r.iy, -r.py);
+    f2 az = __builtin_elementwise_fma(f2{lz, lz}, r.iz, -r.pz), bz = __builtin_elementwise_fma(f2{hz, hz}, r.iz, -r.pz);
     float tnx = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), 0.0f));
     float tny = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), 0.0f));
     float tfx = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
     float tfy = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
     tfx = fminf(tfx * kBestInfl, r.bestp.x);
     tfy = fminf(tfy * kBestInfl, r.bestp.y);
-    px = !(tnx * kTnDefl > tfx) | r.wildx;
-    py = !(tny * kTnDefl > tfy) | r.wildy;
+    px = !(tnx > tfx);
+    py = !(tny > tfy);
     ex = tnx;
     ey = tny;
 }

@@ -66,6 +66,25 @@ __device__ __forceinline__ T load_uniform(const T *p)
 #endif
 }
 
+#ifdef RT_TRAV_STATS
+// Debug build only (make EXTRA=-DRT_TRAV_STATS): traversal counters, summed over all waves.
+// [0] traversals  [1] node groups expanded  [2] triangle records tested
+// [3] triangle tests in which some lane went past the window pre-test
+__device__ unsigned long long g_trav_stats[8];
+extern "C" void rt_debug_trav_stats(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav_stats), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_trav_stats), z, sizeof(z));
+    }
+}
+#define RT_STAT(i, n) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_trav_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define RT_STAT(i, n) do { } while (0)
+#endif
+
 constexpr unsigned long long kHeavyFactor = 8;   // heavy = this many times the mean chunk cost (4 and 16 measured slower)
 constexpr int kSplitLevel = 2;       // cooperative chunks: subtrees of 4^(kSplitLevel+1) triangles
 
@@ -87,12 +106,13 @@ __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, u
 {
     const TriRec T = load_uniform(&tris[node]);
     bool cx = (lanebits >> (2 * j)) & 1u, cy = (lanebits >> (2 * j + 1)) & 1u;
+    RT_STAT(2, 1);
     if (__ballot(cx | cy)) {
         tri_test_pair(T, r, cx, cy);
         // shadow rays (occlusion form): a hit safely below the threshold ends the ray --
         // nothing can pass its node tests any more
-        if (r.best.x < r.stop.x) { r.bestp.x = -1.0f; r.wildx = false; }
-        if (r.best.y < r.stop.y) { r.bestp.y = -1.0f; r.wildy = false; }
+        if (r.best.x < r.stop.x) r.bestp.x = -1.0f;
+        if (r.best.y < r.stop.y) r.bestp.y = -1.0f;
     }
 }
 
@@ -134,17 +154,22 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
     }
     r.ox = f2{oo[0].x, oo[1].x}; r.oy = f2{oo[0].y, oo[1].y}; r.oz = f2{oo[0].z, oo[1].z};
     r.dx = f2{dd[0].x, dd[1].x}; r.dy = f2{dd[0].y, dd[1].y}; r.dz = f2{dd[0].z, dd[1].z};
-    r.ix = f2{slab_inv(dd[0].x), slab_inv(dd[1].x)};
-    r.iy = f2{slab_inv(dd[0].y), slab_inv(dd[1].y)};
-    r.iz = f2{slab_inv(dd[0].z), slab_inv(dd[1].z)};
+    // rays whose origin lies outside the culling extent (or is not finite) are never culled
+    bool wild[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        wild[h] = live[h] & !((fabsf(oo[h].x) <= E) & (fabsf(oo[h].y) <= E) & (fabsf(oo[h].z) <= E) &
+                              (fabsf(dd[h].x) <= 2.0f) & (fabsf(dd[h].y) <= 2.0f) & (fabsf(dd[h].z) <= 2.0f));
+    r.ix = f2{wild[0] ? 0.0f : slab_inv(dd[0].x), wild[1] ? 0.0f : slab_inv(dd[1].x)};
+    r.iy = f2{wild[0] ? 0.0f : slab_inv(dd[0].y), wild[1] ? 0.0f : slab_inv(dd[1].y)};
+    r.iz = f2{wild[0] ? 0.0f : slab_inv(dd[0].z), wild[1] ? 0.0f : slab_inv(dd[1].z)};
+    r.px = f2{wild[0] ? 0.0f : oo[0].x * r.ix.x, wild[1] ? 0.0f : oo[1].x * r.ix.y};
+    r.py = f2{wild[0] ? 0.0f : oo[0].y * r.iy.x, wild[1] ? 0.0f : oo[1].y * r.iy.y};
+    r.pz = f2{wild[0] ? 0.0f : oo[0].z * r.iz.x, wild[1] ? 0.0f : oo[1].z * r.iz.y};
     r.best = f2{b[0], b[1]};
     r.bestp = r.best * kBestInfl;
     r.stop = f2{s[0], s[1]};
     r.idx = -1; r.idy = -1;
-    r.wildx = live[0] & !((fabsf(oo[0].x) <= E) & (fabsf(oo[0].y) <= E) & (fabsf(oo[0].z) <= E) &
-                          (fabsf(dd[0].x) <= 2.0f) & (fabsf(dd[0].y) <= 2.0f) & (fabsf(dd[0].z) <= 2.0f));
-    r.wildy = live[1] & !((fabsf(oo[1].x) <= E) & (fabsf(oo[1].y) <= E) & (fabsf(oo[1].z) <= E) &
-                          (fabsf(dd[1].x) <= 2.0f) & (fabsf(dd[1].y) <= 2.0f) & (fabsf(dd[1].z) <= 2.0f));
 }
 
 // Scene::hit for the pair in `r` (Scene.cu:8-67): on return r.best / r.idx, r.idy hold the
@@ -159,6 +184,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                                          unsigned long long *s_best, uint32_t &cost)
 {
     const TreeView &tv = A.tv;
+    RT_STAT(0, 1);
     unsigned long long pub0 = 0, pub1 = 0;       // what this wave last saw or wrote per ray
     if (COOP) {
         pub0 = pack_hit(r.best.x, -1);
@@ -177,13 +203,11 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
             r.best.x = __uint_as_float((uint32_t)(vx >> 32));
             r.idx = (int32_t)(uint32_t)vx - 1;
             r.bestp.x = r.best.x < r.stop.x ? -1.0f : r.best.x * kBestInfl;
-            if (r.best.x < r.stop.x) r.wildx = false;
         }
         if (vy < pack_hit(r.best.y, r.idy)) {
             r.best.y = __uint_as_float((uint32_t)(vy >> 32));
             r.idy = (int32_t)(uint32_t)vy - 1;
             r.bestp.y = r.best.y < r.stop.y ? -1.0f : r.best.y * kBestInfl;
-            if (r.best.y < r.stop.y) r.wildy = false;
         }
         pub0 = vx < pub0 ? vx : pub0;
         pub1 = vy < pub1 ? vy : pub1;
@@ -205,6 +229,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         for (;;) {
             if (expand) {
                 cost++;
+                RT_STAT(1, 1);
                 if (COOP) merge_in();
                 const NodeGroup G = load_uniform(&tv.groups[lane_get(lvloff, l) + g]);
                 uint32_t key[4], lb = 0, n_pass = 0;

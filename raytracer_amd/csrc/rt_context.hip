@@ -62,7 +62,7 @@ struct rt_context {
     int n_lights = 0;
     uint64_t n_prims = 0;
     float geom_extent = 1.0f;            // max |coordinate| of the uploaded geometry
-    int max_blocks = 2048;
+    int max_blocks = 256;                // blocks per wave-per-SIMD of occupancy (= CUs)
 
     DevView v{};                         // scene + per-pixel state; queue fields = lane 0's
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
@@ -323,9 +323,9 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
         delete c;
         return fail(nullptr, RT_ERR_DEVICE, m);
     }
-    // a persistent grid of what is resident at once (two 256-thread blocks per CU at this
-    // kernel's register count); more blocks only queue behind them (measured: 512 best on C3)
-    c->max_blocks = std::max(1, prop.multiProcessorCount) * 2;
+    // blocks per wave-per-SIMD of occupancy: one 256-thread block per CU.  launch_path makes
+    // the grid what is resident at once; more blocks would only queue behind those.
+    c->max_blocks = std::max(1, prop.multiProcessorCount);
     if (const char *e = std::getenv("RT_MAX_BLOCKS")) c->max_blocks = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("RT_LANES")) c->lanes_wanted = std::max(1, std::min(8, std::atoi(e)));
     int rc = RT_OK;

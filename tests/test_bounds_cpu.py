@@ -19,12 +19,14 @@ def node_pass(box, org, dirn, extent_geom, best=np.float32(1e6)):
     tiny = np.abs(d) < f(1e-30)
     d[tiny] = np.copysign(f(1e-30), d[tiny])
     inv = f(1.0) / d
-    a = (lo[None, :] - org) * inv
-    b = (hi[None, :] - org) * inv
+    oi = (org * inv).astype(f)                               # RayPair::px/py/pz
+    # one fma per plane: fl(lo * inv - oi); the float64 product of two float32 is exact
+    a = (lo[None, :].astype(np.float64) * inv.astype(np.float64) - oi.astype(np.float64)).astype(f)
+    b = (hi[None, :].astype(np.float64) * inv.astype(np.float64) - oi.astype(np.float64)).astype(f)
     tn = np.maximum(np.minimum(a, b).max(1), f(0.0))
-    tf = np.minimum(np.maximum(a, b).min(1) * f(1.000002), best * f(1.000002))
-    rej = tn * f(0.999998) > tf
-    wild = ~(np.abs(org) <= extent).all(1)
+    tf = np.minimum(np.maximum(a, b).min(1) * f(1.000004), best * f(1.000004))
+    rej = tn > tf
+    wild = ~(np.abs(org) <= extent).all(1)                   # zero inverse in the kernel: passes
     return ~rej | wild
 
 

@@ -220,9 +220,9 @@ def main():
                                 if dt else 0.0},
         }
         if world == 1 and not a.no_cpu:
-            crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (512, 288),
-                                                         "c3": (48, 27), "c4": (12, 8),
-                                                         "c5": (4, 2)}[cfg.name]
+            crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (1600, 900),
+                                                         "c3": (192, 108), "c4": (32, 18),
+                                                         "c5": (8, 4)}[cfg.name]
             cpu_spp = spp if cfg.name in ("c1", "c2") else 1
             out["cpu_baseline"] = cpu_baseline(cfg, cpu_spp, crop)
         print(json.dumps(out), flush=True)

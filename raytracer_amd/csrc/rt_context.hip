@@ -36,9 +36,10 @@ struct Lane {
     uint32_t seq = 0;                    // launches that used this lane's dispensers so far
     // chunk-order feedback (rt_kernels.h ChunkFeedback): three sets rotating by launch
     uint32_t *heavy[3] = {nullptr, nullptr, nullptr};
+    uint32_t *early[3] = {nullptr, nullptr, nullptr};
     uint8_t *flag[3] = {nullptr, nullptr, nullptr};
-    uint32_t *n_heavy = nullptr;         // [3]
-    unsigned long long *total = nullptr; // [3]
+    FbCounts *cnt = nullptr;             // [3]
+    uint32_t fb_slots = 0;
     uint32_t fb_seq = 0;                 // path launches so far (set rotation)
 };
 
@@ -164,13 +165,13 @@ int alloc_feedback(rt_context *c, Lane &L)
     int rc;
     for (int s = 0; s < 3; s++) {
         if ((rc = dalloc(c, c->part_allocs, L.heavy[s], chunks))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.early[s], chunks))) return rc;
         if ((rc = dalloc(c, c->part_allocs, L.flag[s], chunks))) return rc;
         RT_HIP(c, hipMemset(L.flag[s], 0, std::max<size_t>(chunks, 1)));
     }
-    if ((rc = dalloc(c, c->part_allocs, L.n_heavy, 3))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, L.total, 3))) return rc;
-    RT_HIP(c, hipMemset(L.n_heavy, 0, 3 * sizeof(uint32_t)));
-    RT_HIP(c, hipMemset(L.total, 0, 3 * sizeof(unsigned long long)));
+    if ((rc = dalloc(c, c->part_allocs, L.cnt, 3))) return rc;
+    RT_HIP(c, hipMemset(L.cnt, 0, 3 * sizeof(FbCounts)));
+    L.fb_slots = (uint32_t)std::max<size_t>(chunks, 1);
     L.fb_seq = 0;
     return RT_OK;
 }
@@ -265,9 +266,10 @@ void timed_path(rt_context *c, Lane &L, const DevView &v, int max_depth)
     // set, zero the one after (nobody touches it during this launch)
     ChunkFeedback f{};
     const int r = (int)((L.fb_seq + 2u) % 3u), w = (int)(L.fb_seq % 3u), z = (int)((L.fb_seq + 1u) % 3u);
-    f.heavy_r = L.heavy[r]; f.n_heavy_r = L.n_heavy + r; f.total_r = L.total + r; f.flag_r = L.flag[r];
-    f.heavy_w = L.heavy[w]; f.n_heavy_w = L.n_heavy + w; f.total_w = L.total + w; f.flag_w = L.flag[w];
-    f.n_heavy_z = L.n_heavy + z; f.total_z = L.total + z;
+    f.cnt_r = L.cnt + r; f.heavy_r = L.heavy[r]; f.early_r = L.early[r]; f.flag_r = L.flag[r];
+    f.cnt_w = L.cnt + w; f.heavy_w = L.heavy[w]; f.early_w = L.early[w]; f.flag_w = L.flag[w];
+    f.cnt_z = L.cnt + z;
+    f.n_slots = L.fb_slots;
     if (e0) (void)hipEventRecord(e0, L.stream);
     launch_path(L.stream, v, L.lo, L.hi - L.lo, max_depth, c->max_blocks, L.ctl,
                 L.ctl->work[L.seq & 1u], L.ctl->work[(L.seq + 1u) & 1u], &f);

@@ -7,14 +7,20 @@
 
 namespace rt {
 
+constexpr int kWorkSlots = 12;
+
 // Per-lane control block, resident in device memory.
 struct Ctl {
-    // Chunk dispensers: [0] waves draw ordinary chunks, [1] blocks draw the heavy ones.
-    // Launch k uses pair k & 1 and zeroes the other for launch k + 1.
-    uint32_t work[2][2];
+    // Chunk dispensers: [0..7] waves draw ordinary chunks, one counter per XCD (each over its
+    // own eighth of the range, the others' when that is used up); [8] blocks draw the heavy
+    // chunks; [9] waves draw the early ones.  Launch k uses set k & 1 and zeroes the other
+    // for launch k + 1.
+    uint32_t work[2][kWorkSlots];
     unsigned long long shadow_total;   // shadow rays cast since rt_reset_stats
     unsigned long long bounce_total;   // bounce (>= 1) rays traced since rt_reset_stats
 };
+
+constexpr int kWorkHeavy = 8, kWorkEarly = 9;
 
 // Struct-of-arrays ray queue of rt_scene_hit: lane i of a wave reads element base + i.
 struct RayQueue {
@@ -34,22 +40,29 @@ struct TreeView {
 
 // Chunk-order feedback of the path kernel (deep trees only).  A chunk's cost is stable
 // from one progressive sample to the next (same pixels), so each launch records which
-// chunks were heavy and the next launch hands those out FIRST, one per block
-// (cooperative form): the kernel then ends with cheap chunks instead of waiting for a
-// straggler that was dispensed last.  Three sets rotate by launch number: `r` was
-// written by the previous launch, `w` is written now, `z` is zeroed now for the next
-// launch to write.  Only an ordering hint -- every chunk is processed exactly once.
+// chunks were costly and the next launch hands those out FIRST: the kernel then ends with
+// cheap chunks instead of waiting for a straggler that was dispensed last.  Classes by
+// cost relative to the mean chunk cost of the previous launch:
+//   heavy (>= 8x): one per BLOCK, cooperative form (four waves share the traversals)
+//   early (>= 4x, then >= 2x): one per wave, before everything else
+// Three sets rotate by launch number: `r` was written by the previous launch, `w` is
+// written now, `z` is zeroed now for the next launch to write.  Only an ordering hint --
+// every chunk is processed exactly once.
+struct FbCounts {
+    uint32_t n_heavy, n_early_a, n_early_b, pad;
+    unsigned long long total;            // summed cost of all chunks
+};
 struct ChunkFeedback {
+    const FbCounts *cnt_r;
     const uint32_t *heavy_r;             // chunk ids that were heavy
-    const uint32_t *n_heavy_r;
-    const unsigned long long *total_r;   // summed cost of all chunks
-    const uint8_t *flag_r;               // per chunk: 1 = in heavy_r
+    const uint32_t *early_r;             // early chunk ids: class a from the front, b from the back
+    const uint8_t *flag_r;               // per chunk: 1 = in heavy_r, 2 = in early_r
+    FbCounts *cnt_w;
     uint32_t *heavy_w;
-    uint32_t *n_heavy_w;
-    unsigned long long *total_w;
+    uint32_t *early_w;
     uint8_t *flag_w;
-    uint32_t *n_heavy_z;
-    unsigned long long *total_z;
+    FbCounts *cnt_z;
+    uint32_t n_slots;                    // entries of the heavy / early arrays (= chunks of the range)
 };
 
 struct DevView {

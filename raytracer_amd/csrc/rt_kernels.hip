@@ -17,6 +17,7 @@
 #include "rt_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "rt_device.h"
 
@@ -83,6 +84,19 @@ extern "C" void rt_debug_trav_stats(unsigned long long *out, int reset)
 #define RT_STAT(i, n) do { if ((threadIdx.x & 63u) == 0) atomicAdd(&g_trav_stats[i], (unsigned long long)(n)); } while (0)
 #else
 #define RT_STAT(i, n) do { } while (0)
+#endif
+#ifdef RT_TRAV_LOG
+// Debug build only (make EXTRA=-DRT_TRAV_LOG): per-chunk timeline of the launches whose p0
+// equals g_log_p0 (one stream's pixel range)
+struct ChunkLog { unsigned long long t0, t1; unsigned cost, coop; };
+__device__ ChunkLog g_log[1 << 17];
+__device__ unsigned g_log_p0 = 0xffffffffu;
+extern "C" void rt_debug_log(void *out, unsigned p0, unsigned n)
+{
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_log), sizeof(ChunkLog) * n);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_log_p0), &p0, sizeof(p0));
+}
 #endif
 
 constexpr unsigned long long kHeavyFactor = 8;   // heavy = this many times the mean chunk cost (4 and 16 measured slower)
@@ -371,12 +385,15 @@ struct PathArgs {
     bool occlusion;                  // shadow rays may stop at the first hit below the threshold
     Ctl *ctl;
     ChunkFeedback fb;
+    uint32_t heavy_x4;               // heavy = cost >= heavy_x4 / 4 times the mean chunk cost
+    uint32_t dbg;
 };
 // Per-launch values every chunk shares (kept apart from the kernel argument block, which
 // stays read-only in the constant address space).
 struct ChunkEnv {
     uint32_t lvloff;                 // lane l: first group of level l
     uint32_t heavy_cost;             // cost from which a chunk counts as heavy (feedback)
+    uint32_t mean_cost;              // mean chunk cost of the previous launch (0: unknown)
     bool feedback;
 };
 
@@ -458,6 +475,9 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
     const int L = v.n_lights;
     const float E = A.T.tv.extent;
     uint32_t cost = 0, n_shadow = 0, n_bounce = 0;
+#ifdef RT_TRAV_LOG
+    const unsigned long long tlog0 = (unsigned long long)wall_clock64();
+#endif
     if (COOP && threadIdx.x == 0)
         *s_cost = 0;                             // ordered before the adds by traverse()'s barriers
 
@@ -656,15 +676,25 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         if (wib != 0)
             return;
     }
+#ifdef RT_TRAV_LOG
+    if (lane == 0 && g_log_p0 == A.p0 && chunk < (1u << 17))
+        g_log[chunk] = ChunkLog{tlog0, (unsigned long long)wall_clock64(), cost, COOP ? 1u : 0u};
+#endif
     if (lane == 0) {
         if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
         if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
         if (env.feedback) {
             const bool heavy = cost >= env.heavy_cost;
-            A.fb.flag_w[chunk] = heavy ? 1 : 0;
-            atomicAdd(A.fb.total_w, (unsigned long long)cost);
+            const bool early_a = !heavy && env.mean_cost && cost >= 4u * env.mean_cost;
+            const bool early_b = !heavy && !early_a && env.mean_cost && cost >= 2u * env.mean_cost;
+            A.fb.flag_w[chunk] = heavy ? 1 : (early_a | early_b) ? 2 : 0;
+            atomicAdd(&A.fb.cnt_w->total, (unsigned long long)cost);
             if (heavy)
-                A.fb.heavy_w[atomicAdd(A.fb.n_heavy_w, 1u)] = chunk;
+                A.fb.heavy_w[atomicAdd(&A.fb.cnt_w->n_heavy, 1u)] = chunk;
+            else if (early_a)
+                A.fb.early_w[atomicAdd(&A.fb.cnt_w->n_early_a, 1u)] = chunk;
+            else if (early_b)
+                A.fb.early_w[A.fb.n_slots - 1u - atomicAdd(&A.fb.cnt_w->n_early_b, 1u)] = chunk;
         }
     }
 }
@@ -693,27 +723,31 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     env.feedback = dynamic && A.fb.flag_w != nullptr;
     env.heavy_cost = 0xffffffffu;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        work_next[0] = 0u;               // the next launch's dispensers (stream-ordered after us)
-        work_next[1] = 0u;
-        if (A.fb.n_heavy_z) {            // and the feedback set the next launch writes
-            *A.fb.n_heavy_z = 0u;
-            *A.fb.total_z = 0ull;
+    env.mean_cost = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
+        work_next[threadIdx.x] = 0u;     // the next launch's dispensers (stream-ordered after us)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.fb.cnt_z) {
+        FbCounts z{};                    // and the feedback set the next launch writes
+        *A.fb.cnt_z = z;
+    }
+    uint32_t n_heavy = 0, n_early_a = 0, n_early_b = 0;
+    if (env.feedback) {
+        const FbCounts cr = *A.fb.cnt_r;
+        n_heavy = cr.n_heavy; n_early_a = cr.n_early_a; n_early_b = cr.n_early_b;
+        if (cr.total) {
+            env.mean_cost = (uint32_t)std::max<unsigned long long>(cr.total / std::max(n_chunks, 1u), 12ull);
+            env.heavy_cost = (uint32_t)std::max<unsigned long long>(
+                (unsigned long long)A.heavy_x4 * cr.total / (4ull * std::max(n_chunks, 1u)), 96ull);
         }
     }
-    uint32_t n_heavy = 0;
-    if (env.feedback) {
-        n_heavy = *A.fb.n_heavy_r;
-        unsigned long long total = *A.fb.total_r;
-        if (total)
-            env.heavy_cost = (uint32_t)std::max<unsigned long long>(kHeavyFactor * total / std::max(n_chunks, 1u), 96ull);
-    }
+    if (A.dbg & 1u) { n_early_a = 0; n_early_b = 0; }
+    const bool ordered = CULL && (n_heavy | n_early_a | n_early_b);
 
     // phase 1: the previous sample's heavy chunks, one per block
     if (CULL && n_heavy) {
         for (;;) {
             if (threadIdx.x == 0)
-                s_chunk = atomicAdd(&work[1], 1u);
+                s_chunk = atomicAdd(&work[kWorkHeavy], 1u);
             __syncthreads();
             const uint32_t d = s_chunk;
             __syncthreads();
@@ -722,25 +756,44 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
             path_chunk<CULL, true, DEPTH0>(A, env, A.fb.heavy_r[d], lane, wib, s_best, &s_cost, st);
         }
     }
-
-    // phase 2: everything else, one per wave
-    const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
-    uint32_t next_chunk = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    for (;;) {
-        uint32_t chunk = 0;
-        if (dynamic) {
-            if (lane == 0)
-                chunk = atomicAdd(&work[0], 1u);
-            chunk = __builtin_amdgcn_readfirstlane(chunk);
-        } else {
-            chunk = next_chunk;
-            next_chunk += n_waves;
+    // phase 2, one chunk per wave at a time: first the previous sample's early chunks,
+    // costliest class first (stage 0), then everything else (stages 1..8).  Workgroups go
+    // to the XCDs round-robin (blockIdx % 8), and every XCD has its own L2: each XCD works
+    // through its own eighth of the range first -- a band of the image, hence a part of the
+    // tree its L2 can hold -- and helps with the others' only when that is used up.
+    if (dynamic) {
+        const uint32_t per = (n_chunks + 7u) / 8u;
+        const uint32_t xcd = blockIdx.x & 7u;
+        const uint32_t n_early = n_early_a + n_early_b;
+        for (uint32_t stage = n_early ? 0u : 1u; stage <= 8u; stage++) {
+            const uint32_t y = (xcd + stage - 1u) & 7u;              // stages 1..8
+            const uint32_t base = y * per;
+            const uint32_t size = stage == 0u ? n_early : base < n_chunks ? min(per, n_chunks - base) : 0u;
+            uint32_t *counter = &work[stage == 0u ? (uint32_t)kWorkEarly : y];
+            for (;;) {
+                uint32_t d = size;
+                if (size) {
+                    if (lane == 0)
+                        d = atomicAdd(counter, 1u);
+                    d = __builtin_amdgcn_readfirstlane(d);
+                }
+                if (d >= size)
+                    break;
+                uint32_t chunk = base + d;
+                if (stage == 0u)
+                    chunk = d < n_early_a ? A.fb.early_r[d] : A.fb.early_r[A.fb.n_slots - 1u - (d - n_early_a)];
+                else if (ordered) {
+                    const uint8_t fl = A.fb.flag_r[chunk];
+                    if ((fl == 1 && n_heavy) || (fl == 2 && n_early))
+                        continue;                // went out with the heavy / early ones
+                }
+                path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st);
+            }
         }
-        if (chunk >= n_chunks)
-            break;
-        if (CULL && n_heavy && A.fb.flag_r[chunk])
-            continue;                            // went out with the heavy ones
-        path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st);
+    } else {
+        const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
+        for (uint32_t chunk = (blockIdx.x * kBlock + threadIdx.x) >> 6; chunk < n_chunks; chunk += n_waves)
+            path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st);
     }
 }
 
@@ -755,10 +808,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const TravArgs T, RayQueue
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_chunks = (count + kPathChunk - 1u) / kPathChunk;
     const uint32_t lvloff = T.tv.level_off[lane & (kMaxLevels - 1)];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        work_next[0] = 0u;
-        work_next[1] = 0u;
-    }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
+        work_next[threadIdx.x] = 0u;
     const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
     uint32_t next_chunk = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     for (;;) {
@@ -917,6 +968,9 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     A.ctl = ctl;
     const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
     if (fb) A.fb = *fb;
+    static const int heavy_env = std::getenv("RT_HEAVY_X4") ? std::atoi(std::getenv("RT_HEAVY_X4")) : 0;
+    A.dbg = std::getenv("RT_DBG") ? (uint32_t)std::atoi(std::getenv("RT_DBG")) : 0u;
+    A.heavy_x4 = heavy_env > 0 ? (uint32_t)heavy_env : 4u * (uint32_t)kHeavyFactor;
     const bool d0 = max_depth == 0;
     // Waves per SIMD (measured on MI355X, 1080p and 4K frames on two streams): a launch with
     // tens of thousands of chunks is throughput-bound and wants four; over a shallow tree

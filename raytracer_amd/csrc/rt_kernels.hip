@@ -192,17 +192,13 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
 // lvloff: lane l holds the first group of level l.
 // COOP: called by all four waves of the block with identical rays; s_best is the block's
 // LDS merge array (128 entries).  Every wave returns the block's common answer.
-template <bool CULL, bool COOP_T>
+template <bool CULL, bool COOP>
 __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, RayPair &r,
                                          uint32_t lane, uint32_t wib,
-                                         unsigned long long *s_best, uint32_t &cost,
-                                         bool coop_now = true)
+                                         unsigned long long *s_best, uint32_t &cost)
 {
     const TreeView &tv = A.tv;
     RT_STAT(0, 1);
-    // coop_now (block-uniform): this call is shared by the block's four waves; otherwise it
-    // is this wave's own traversal even in the cooperative form of the chunk
-    const bool COOP = COOP_T && coop_now;
     unsigned long long pub0 = 0, pub1 = 0;       // what this wave last saw or wrote per ray
     if (COOP) {
         pub0 = pack_hit(r.best.x, -1);
@@ -415,7 +411,6 @@ struct RayState {
     float thr;                       // its Scene.cu:227 threshold |o - l| - 0.01
     v3 tangent, beta, res;           // !DEPTH0 only
     static constexpr int kSlots = DEPTH0 ? 16 : 25;
-    static constexpr int kContribSlot = 12, kThrSlot = 15;   // rows of save() / load()
 
     __device__ __forceinline__ void save(float *st) const
     {
@@ -513,22 +508,15 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         pair_set(w, ro, rd, inf2, none2, alive, E);
     }
 
-    // Cooperative form: the closest hit of a bounce is one traversal shared by the four waves
-    // (subtrees split among them); its shadow rays are four traversals at a time, light
-    // j0 + wib on wave wib, whose verdicts the waves exchange through their LDS columns and
-    // add in light order, so every wave ends the round with the same `le`.
-    int bounce = 0, j = -1, j0 = 0;
-    bool do_trav = true;
+    int bounce = 0, j = -1;
     for (;;) {
-        if (do_trav) {
-            S[0].save(st);
-            S[1].save(st + State::kSlots * kBlock);
-            asm volatile("" ::: "memory");
-            traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost, j < 0);
-            asm volatile("" ::: "memory");
-            S[0].load(st);
-            S[1].load(st + State::kSlots * kBlock);
-        }
+        S[0].save(st);
+        S[1].save(st + State::kSlots * kBlock);
+        asm volatile("" ::: "memory");
+        traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost);
+        asm volatile("" ::: "memory");
+        S[0].load(st);
+        S[1].load(st + State::kSlots * kBlock);
         if (j < 0) {
             // ---- closest hit of this bounce: PathTracer.cu:27-64
 #pragma unroll
@@ -580,47 +568,15 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                                            : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
                     blocked = length(sub(hp, sr.o)) < S[h].thr;
                 }
-                if (COOP)
-                    cast[h] = !blocked;                      // what the other waves need to know
-                else if (!blocked)                           // res += ... in light order (Scene.cu:120)
+                if (!blocked)                                // res += ... in light order (Scene.cu:120)
                     S[h].le = add(S[h].le, S[h].contrib);
-            }
-            if (COOP) {
-                // exchange: thr slot = +1 "add contrib" / -1 "nothing to add"
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    S[h].thr = cast[h] ? 1.0f : -1.0f;
-                S[0].save(st);
-                S[1].save(st + State::kSlots * kBlock);
-                __syncthreads();
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    for (int k = 0; k < 4; k++) {
-                        const float *sw = st + (k - (int)wib) * 64 + h * State::kSlots * kBlock;
-                        if (sw[State::kThrSlot * kBlock] > 0.0f)
-                            S[h].le = add(S[h].le, mk3(sw[(State::kContribSlot + 0) * kBlock],
-                                                       sw[(State::kContribSlot + 1) * kBlock],
-                                                       sw[(State::kContribSlot + 2) * kBlock]));
-                    }
-                __syncthreads();                             // columns are free again
             }
         }
 
         // ---- the next light some lane of the chunk casts a shadow ray towards
         bool more = false;
         if (__ballot(ishit[0] | ishit[1])) {
-            // solo: scan on from light j + 1; cooperative: this wave's light of the next round
-            const int j_first = COOP ? j0 + (int)wib : j + 1;
-            const int j_end = COOP ? (j0 < L ? j_first + 1 : j_first) : L;
-            if (COOP && j0 < L) {
-                more = true;                                 // the round happens, cast or not
-                j = j_first;
-                j0 += 4;
-                do_trav = false;
-                cast[0] = false; cast[1] = false;
-            }
-            for (int jj = j_first; jj < j_end && jj < L; jj++) {
-                j = jj;
+            for (j = j + 1; j < L; j++) {
                 const LightRec light = load_uniform(&v.lights[j]);
                 v3 so[2], sd[2];
                 float sb[2], ss[2];
@@ -649,12 +605,9 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                     n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
                     pair_set(w, so, sd, sb, ss, cast, E);
                     more = true;
-                    do_trav = true;
                     break;
                 }
             }
-            if (!COOP && !more)
-                j = L;
         }
         if (more)
             continue;
@@ -706,8 +659,6 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         n_bounce += (uint32_t)__popcll(a0) + (uint32_t)__popcll(a1);
         bounce++;
         j = -1;
-        j0 = 0;
-        do_trav = true;
         pair_set(w, ro, rd, inf2, none2, alive, E);
     }
 
@@ -721,11 +672,8 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         if (lane == 0) atomicAdd(s_cost, cost);
         __syncthreads();
         cost = *s_cost;
-        if (wib != 0) {
-            // this wave's own shadow rays (its lights of every round)
-            if (lane == 0 && n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+        if (wib != 0)
             return;
-        }
     }
 #ifdef RT_TRAV_LOG
     if (lane == 0 && g_log_p0 == A.p0 && chunk < (1u << 17))
@@ -1033,8 +981,6 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // cooperative form shortens (measured on 1/8 partitions of C3 and C4: 2x and 4x best).
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves * (kBlock / 64);
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
-    static const int heavy_env = std::getenv("RT_HEAVY_X4") ? std::atoi(std::getenv("RT_HEAVY_X4")) : 0;
-    if (heavy_env > 0) A.heavy_x4 = (uint32_t)heavy_env;
     if (v.cull) {
         if (!d0)             k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else if (waves == 4) k_path<true, true, 4><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);

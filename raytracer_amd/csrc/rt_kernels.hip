@@ -967,13 +967,14 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
     if (fb) A.fb = *fb;
     const bool d0 = max_depth == 0;
-    // Waves per SIMD (measured on MI355X, 1080p and 4K frames on two streams): a launch with
-    // tens of thousands of chunks is throughput-bound and wants four; over a shallow tree
-    // (cheap, uniform chunks) three; a deep tree with few chunks is bound by its longest
+    // Waves per SIMD (measured on MI355X, whole frames and 1/2 .. 1/8 partitions): a tree far
+    // larger than an XCD's 4 MB L2 (C4: 871 k triangles = 84 MB of records) waits on memory at
+    // almost every step and wants four; a shallow tree (cheap, uniform chunks) three; a tree
+    // that mostly sits in L2 (C3: 69 k triangles) is bound by VALU issue and by its longest
     // chunks, which run fastest at two.  The grid is what is resident at once.
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
     int waves = 2;
-    if (d0 && v.cull) waves = n_chunks >= 16384u ? 4 : (dynamic ? 2 : 3);
+    if (d0 && v.cull) waves = v.n_tris >= 200000 ? 4 : (dynamic ? 2 : 3);
     const uint32_t g = grid_for_chunks(n, max_blocks * waves);
     // Cooperative form from which multiple of the mean chunk cost on: a launch with many
     // chunks per resident wave is throughput-bound, and sharing a chunk among four waves

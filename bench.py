@@ -68,13 +68,27 @@ def measured_traffic(cfg_name, kernel):
     (profiles/r01_traffic_k_path.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
     None if there is no profile for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_traffic_k_path.json")
     try:
         with open(path) as f:
             d = json.load(f)
         return float(d[cfg_name][kernel]["bytes_per_launch"])
     except (OSError, KeyError, ValueError, TypeError):
         return None
+
+
+def measured_counter(cfg_name, counter):
+    """Per-launch value of an SQ counter of k_path from the committed PMC summary
+    (profiles/r01_<cfg>_pmc_sq.txt, written by tools/pmc_summary.py).  None if absent."""
+    path = os.path.join(ROOT, "profiles", f"r01_{cfg_name}_pmc_sq.txt")
+    try:
+        for line in open(path):
+            f = line.split()
+            if f and f[0] == counter:
+                return float(f[f.index("launch") + 1])
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg, spp, crop_wh):
@@ -216,9 +230,21 @@ def main():
             "scan_equivalent": {"model": "SURVEY 8(d): every ray streams every primitive, one "
                                          "fetch per 256 rays",
                                 "gbs": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
-                                "pair_tests_per_s": tests / (dt / a.steps * 1e-3) / a.steps
-                                if dt else 0.0},
+                                "pair_tests_per_s": tests / dt if dt else 0.0},
         }
+        # What actually bounds the kernel: VALU issue.  Instructions per launch come from the
+        # committed SQ_INSTS_VALU pass (same command, profiles/), the duration is live; a
+        # wave64 VALU instruction occupies its SIMD for 4 cycles, and the streams' launches
+        # share the chip.
+        valu = measured_counter(cfg.name, "SQ_INSTS_VALU")
+        if valu and k_ms > 0:
+            prop = torch.cuda.get_device_properties(dev)
+            simds = prop.multi_processor_count * 4
+            clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
+            share = max(1, int(st.streams))
+            out["valu_issue"] = {"insts_per_launch": valu, "source": f"profiles/r01_{cfg.name}_pmc_sq.txt",
+                                 "simds": simds, "clock_hz": clk_hz,
+                                 "frac_of_issue_slots": valu * 4.0 / (k_ms * 1e-3 * simds * clk_hz / share)}
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (1600, 900),
                                                          "c3": (192, 108), "c4": (32, 18),

@@ -87,6 +87,15 @@ struct DevView {
     float *first_t;
 };
 
+// Records of one batch of samples of the depth-0 pipeline (k_primary -> k_shadow -> k_accum),
+// struct-of-arrays, sample-major: element s * stride + p of every array.
+//   f[0..2] hit position, overwritten by k_shadow with the sample's radiance
+//   f[3..5] normal   f[6] dot(-dir, normal)   f[7] model index as int bits, -1 = the ray missed
+struct SampleBatch {
+    float *f[8];
+    uint32_t stride;                // pixels of the partition
+};
+
 // One progressive sample of local pixels [p0, p0 + n): the whole path of every pixel
 // (kernel.cu:50-79 -> pathTracer) in ONE launch.  work / work_next: this launch's and the
 // next launch's pair of dispenser counters; fb may be null (no feedback).
@@ -94,6 +103,16 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
                  const ChunkFeedback *fb);
 constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (two per lane)
+
+// Depth-0 pipeline over the whole partition (n pixels), one batch of n_samples samples.
+void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
+                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
+                    uint32_t *work_next, const ChunkFeedback *fb);
+void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
+                   const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
+                   uint32_t *work_next);
+void launch_accum(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
+                  const SampleBatch &b, int cnt0);
 
 // Scene::hit on a queue of caller rays (rt_scene_hit).
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

@@ -396,6 +396,23 @@ struct ChunkEnv {
     bool feedback;
 };
 
+// Feedback of one finished chunk (called by one lane): its class for the next launch.
+__device__ __forceinline__ void record_cost(const ChunkFeedback &fb, const ChunkEnv &env,
+                                            uint32_t chunk, uint32_t cost)
+{
+    const bool heavy = cost >= env.heavy_cost;
+    const bool early_a = !heavy && env.mean_cost && cost >= 4u * env.mean_cost;
+    const bool early_b = !heavy && !early_a && env.mean_cost && cost >= 2u * env.mean_cost;
+    fb.flag_w[chunk] = heavy ? 1 : (early_a | early_b) ? 2 : 0;
+    atomicAdd(&fb.cnt_w->total, (unsigned long long)cost);
+    if (heavy)
+        fb.heavy_w[atomicAdd(&fb.cnt_w->n_heavy, 1u)] = chunk;
+    else if (early_a)
+        fb.early_w[atomicAdd(&fb.cnt_w->n_early_a, 1u)] = chunk;
+    else if (early_b)
+        fb.early_w[fb.n_slots - 1u - atomicAdd(&fb.cnt_w->n_early_b, 1u)] = chunk;
+}
+
 // What one ray of a lane carries from one traversal to the next.  A traversal wants every
 // VGPR it can get (occupancy hides its scalar-load latency), so this state is parked in LDS
 // for its duration: one dword column per thread, kSlots rows (conflict-free).
@@ -682,19 +699,8 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
     if (lane == 0) {
         if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
         if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
-        if (env.feedback) {
-            const bool heavy = cost >= env.heavy_cost;
-            const bool early_a = !heavy && env.mean_cost && cost >= 4u * env.mean_cost;
-            const bool early_b = !heavy && !early_a && env.mean_cost && cost >= 2u * env.mean_cost;
-            A.fb.flag_w[chunk] = heavy ? 1 : (early_a | early_b) ? 2 : 0;
-            atomicAdd(&A.fb.cnt_w->total, (unsigned long long)cost);
-            if (heavy)
-                A.fb.heavy_w[atomicAdd(&A.fb.cnt_w->n_heavy, 1u)] = chunk;
-            else if (early_a)
-                A.fb.early_w[atomicAdd(&A.fb.cnt_w->n_early_a, 1u)] = chunk;
-            else if (early_b)
-                A.fb.early_w[A.fb.n_slots - 1u - atomicAdd(&A.fb.cnt_w->n_early_b, 1u)] = chunk;
-        }
+        if (env.feedback)
+            record_cost(A.fb, env, chunk, cost);
     }
 }
 
@@ -708,53 +714,50 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
 // them in the per-bounce shading code, none inside the traversal loops).  More resident
 // waves hide the traversal's scalar-load latency, fewer run each chunk faster; which wins
 // depends on how many chunks a launch has (launch_path).
-template <bool CULL, bool DEPTH0, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32_t *__restrict__ work,
-                                                 uint32_t *__restrict__ work_next, int dynamic)
+// The dispatch every chunked kernel here shares.  solo(chunk) runs one chunk on the calling
+// wave, coop(chunk) runs it on the whole block (cooperative form; needs feedback).
+template <bool CULL, class Solo, class Coop>
+__device__ __forceinline__ void run_chunks(uint32_t n_chunks, const ChunkFeedback &fb,
+                                           uint32_t heavy_x4, uint32_t *__restrict__ work,
+                                           uint32_t *__restrict__ work_next, int dynamic,
+                                           ChunkEnv &env, uint32_t *s_chunk, Solo solo, Coop coop)
 {
-    __shared__ unsigned long long s_best[128];
-    __shared__ uint32_t s_cost, s_chunk;
-    __shared__ float s_stash[2 * RayState<DEPTH0>::kSlots][kBlock];
-    float *st = &s_stash[0][threadIdx.x];
-    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
-    ChunkEnv env;
-    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
-    env.feedback = dynamic && A.fb.flag_w != nullptr;
+    const uint32_t lane = threadIdx.x & 63u;
+    env.feedback = dynamic && fb.flag_w != nullptr;
     env.heavy_cost = 0xffffffffu;
     env.mean_cost = 0u;
     if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
         work_next[threadIdx.x] = 0u;     // the next launch's dispensers (stream-ordered after us)
-    if (blockIdx.x == 0 && threadIdx.x == 0 && A.fb.cnt_z) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fb.cnt_z) {
         FbCounts z{};                    // and the feedback set the next launch writes
-        *A.fb.cnt_z = z;
+        *fb.cnt_z = z;
     }
     uint32_t n_heavy = 0, n_early_a = 0, n_early_b = 0;
     if (env.feedback) {
-        const FbCounts cr = *A.fb.cnt_r;
+        const FbCounts cr = *fb.cnt_r;
         n_heavy = cr.n_heavy; n_early_a = cr.n_early_a; n_early_b = cr.n_early_b;
         if (cr.total) {
             env.mean_cost = (uint32_t)std::max<unsigned long long>(cr.total / std::max(n_chunks, 1u), 12ull);
             env.heavy_cost = (uint32_t)std::max<unsigned long long>(
-                (unsigned long long)A.heavy_x4 * cr.total / (4ull * std::max(n_chunks, 1u)), 96ull);
+                (unsigned long long)heavy_x4 * cr.total / (4ull * std::max(n_chunks, 1u)), 96ull);
         }
     }
     const bool ordered = CULL && (n_heavy | n_early_a | n_early_b);
 
-    // phase 1: the previous sample's heavy chunks, one per block
+    // phase 1: the previous launch's heavy chunks, one per block
     if (CULL && n_heavy) {
         for (;;) {
             if (threadIdx.x == 0)
-                s_chunk = atomicAdd(&work[kWorkHeavy], 1u);
+                *s_chunk = atomicAdd(&work[kWorkHeavy], 1u);
             __syncthreads();
-            const uint32_t d = s_chunk;
+            const uint32_t d = *s_chunk;
             __syncthreads();
             if (d >= n_heavy)
                 break;
-            path_chunk<CULL, true, DEPTH0>(A, env, A.fb.heavy_r[d], lane, wib, s_best, &s_cost, st);
+            coop(fb.heavy_r[d]);
         }
     }
-    // phase 2, one chunk per wave at a time: first the previous sample's early chunks,
+    // phase 2, one chunk per wave at a time: first the previous launch's early chunks,
     // costliest class first (stage 0), then everything else (stages 1..8).  Workgroups go
     // to the XCDs round-robin (blockIdx % 8), and every XCD has its own L2: each XCD works
     // through its own eighth of the range first -- a band of the image, hence a part of the
@@ -779,20 +782,322 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
                     break;
                 uint32_t chunk = base + d;
                 if (stage == 0u)
-                    chunk = d < n_early_a ? A.fb.early_r[d] : A.fb.early_r[A.fb.n_slots - 1u - (d - n_early_a)];
+                    chunk = d < n_early_a ? fb.early_r[d] : fb.early_r[fb.n_slots - 1u - (d - n_early_a)];
                 else if (ordered) {
-                    const uint8_t fl = A.fb.flag_r[chunk];
+                    const uint8_t fl = fb.flag_r[chunk];
                     if ((fl == 1 && n_heavy) || (fl == 2 && n_early))
                         continue;                // went out with the heavy / early ones
                 }
-                path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st);
+                solo(chunk);
             }
         }
     } else {
         const uint32_t n_waves = (gridDim.x * kBlock) >> 6;
         for (uint32_t chunk = (blockIdx.x * kBlock + threadIdx.x) >> 6; chunk < n_chunks; chunk += n_waves)
-            path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st);
+            solo(chunk);
     }
+}
+
+template <bool CULL, bool DEPTH0, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32_t *__restrict__ work,
+                                                 uint32_t *__restrict__ work_next, int dynamic)
+{
+    __shared__ unsigned long long s_best[128];
+    __shared__ uint32_t s_cost, s_chunk;
+    __shared__ float s_stash[2 * RayState<DEPTH0>::kSlots][kBlock];
+    float *st = &s_stash[0][threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    run_chunks<CULL>(
+        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t chunk) { path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
+        [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+}
+
+// ------------------------------------------------------------------ depth 0 in three kernels
+// With max_depth = 0 (primary hit + direct light, the benchmark mode) the samples of a pixel
+// depend on one another only through the closest hit of the camera ray: the pixel's Philox
+// counter advances by 1 (jitter) + 1 (PathTracer.cu:27) + one per light if the ray hit
+// (Scene.cu:87) + 1 if the BRDF sample is usable (PathTracer.cu:77, the discarded trace of the
+// next iteration).  The shadow rays -- most of the work -- do not feed back into it.  So:
+//   k_primary  for a batch of S samples, per chunk of 128 pixels and sample after sample: jitter,
+//              camera ray, closest hit, hit record; writes one 32-byte record per
+//              pixel-sample and advances the RNG counters.  This is the only sequential chain.
+//   k_shadow   over all S x chunks units at once: lights, shadow rays, radiance of the sample.
+//   k_accum    per pixel, in sample order: the running mean of kernel.cu:65-66,75,77.
+// k_shadow of one batch overlaps k_primary of the next on a second stream; a step is then
+// as long as its throughput allows, not spp times its costliest chunk (Multi-GPU).
+struct BatchArgs {
+    DevView v;
+    TravArgs T;
+    uint32_t n;                      // pixels of the partition
+    uint32_t n_samples;              // samples in this batch
+    SampleBatch b;
+    bool occlusion;
+    Ctl *ctl;
+    ChunkFeedback fb;
+    uint32_t heavy_x4;
+};
+
+template <bool CULL, bool COOP>
+__device__ __forceinline__ void primary_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t chunk,
+                                              uint32_t lane, uint32_t wib,
+                                              unsigned long long *s_best, uint32_t *s_cost)
+{
+    const DevView &v = A.v;
+    const bool writer = !COOP || wib == 0;
+    const int L = v.n_lights;
+    const float E = A.T.tv.extent;
+    uint32_t cost = 0;
+    if (COOP && threadIdx.x == 0)
+        *s_cost = 0;
+    uint32_t p[2], pix[2], draw[2];
+    bool mine[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t pl = chunk * kPathChunk + (uint32_t)h * 64u + lane;
+        mine[h] = pl < A.n;
+        p[h] = min(pl, A.n - 1u);
+        pix[h] = v.pixmap[p[h]];
+        draw[h] = v.rng_ctr[p[h]];
+    }
+    const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
+    for (uint32_t s = 0; s < A.n_samples; s++) {
+        RayPair w;
+        {
+            v3 ro[2], rd[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                // kernel.cu:65-73 with the H4 convention: the jitter is (.x, .y) of one
+                // curand_uniform4 of the pixel's own stream
+                float u[4];
+                pixel_uniform4(pix[h], draw[h], u);
+                draw[h] += 1u;
+                int x = (int)(pix[h] % (uint32_t)v.width), y = (int)(pix[h] / (uint32_t)v.width);
+                Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
+                ro[h] = r.o; rd[h] = r.d;
+            }
+            pair_set(w, ro, rd, inf2, none2, mine, E);
+        }
+        traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (!mine[h])
+                continue;
+            const float t = h ? w.best.y : w.best.x;
+            const int32_t id = h ? w.idy : w.idx;
+            const bool ishit = scene_ishit(t) && id >= 0;
+            // draws of the bounce: tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
+            const uint32_t bd = draw[h];
+            draw[h] += 1u + (ishit ? (uint32_t)L : 0u);
+            float rec[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            int model = -1;                                  // miss: PathTracer.cu:64 -> return res
+            if (ishit) {
+                Ray r;
+                r.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+                r.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+                Hit H;
+                fill_hit(v, r, id, H);
+                const float wo_y = local_y(H, neg(r.d));     // Object.cu:107-110 on wo = -r.dir
+                // PathTracer.cu:76-77: only whether the BRDF sample is usable matters at depth 0
+                float u[4];
+                pixel_uniform4(pix[h], bd, u);
+                v3 wi;
+                float pdf;
+                v3 f = rec_sample_f_y(H, v.models[H.model], wo_y, wi, pdf, u[0], u[1]);
+                if (!(pdf < 0.0001f || length(f) < 0.0001f))
+                    draw[h] += 1u;                           // the next iteration's draw (:27) before its break (:64)
+                rec[0] = H.pos.x; rec[1] = H.pos.y; rec[2] = H.pos.z;
+                rec[3] = H.normal.x; rec[4] = H.normal.y; rec[5] = H.normal.z;
+                rec[6] = wo_y;
+                model = H.model;
+            }
+            if (writer) {
+                const size_t i = (size_t)s * A.b.stride + p[h];
+#pragma unroll
+                for (int k = 0; k < 7; k++)
+                    A.b.f[k][i] = rec[k];
+                A.b.f[7][i] = __int_as_float(model);
+                if (s + 1u == A.n_samples) {                 // id / t buffers: the last sample's primary hit
+                    v.first_id[p[h]] = id;
+                    v.first_t[p[h]] = t;
+                }
+            }
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            if (mine[h])
+                v.rng_ctr[p[h]] = draw[h];
+    }
+    if (COOP) {
+        if (lane == 0) atomicAdd(s_cost, cost);
+        __syncthreads();
+        cost = *s_cost;
+        if (wib != 0)
+            return;
+    }
+    if (lane == 0 && env.feedback)
+        record_cost(A.fb, env, chunk, cost);
+}
+
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32_t *__restrict__ work,
+                                                       uint32_t *__restrict__ work_next, int dynamic)
+{
+    __shared__ unsigned long long s_best[128];
+    __shared__ uint32_t s_cost, s_chunk;
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    run_chunks<CULL>(
+        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t chunk) { primary_chunk<CULL, false>(A, env, chunk, lane, wib, nullptr, nullptr); },
+        [&](uint32_t chunk) { primary_chunk<CULL, true>(A, env, chunk, lane, wib, s_best, &s_cost); });
+}
+
+// One unit = 128 pixel-samples: sample s = unit / chunks, pixels of chunk unit % chunks.
+template <bool CULL>
+__device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
+                                             uint32_t n_chunks, uint32_t lane, float *st)
+{
+    using State = RayState<true>;
+    const DevView &v = A.v;
+    const int L = v.n_lights;
+    const float E = A.T.tv.extent;
+    const uint32_t s = unit / n_chunks, chunk = unit - s * n_chunks;
+    uint32_t cost = 0, n_shadow = 0;
+    State S[2];
+    bool hit[2], cast[2] = {false, false};
+    size_t idx[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t pl = chunk * kPathChunk + (uint32_t)h * 64u + lane;
+        idx[h] = (size_t)s * A.b.stride + min(pl, A.n - 1u);
+        S[h] = State{};
+        S[h].model = pl < A.n ? __float_as_int(A.b.f[7][idx[h]]) : -1;
+        hit[h] = S[h].model >= 0;
+        if (hit[h]) {
+            S[h].pos = mk3(A.b.f[0][idx[h]], A.b.f[1][idx[h]], A.b.f[2][idx[h]]);
+            S[h].normal = mk3(A.b.f[3][idx[h]], A.b.f[4][idx[h]], A.b.f[5][idx[h]]);
+            S[h].wo_y = A.b.f[6][idx[h]];
+        }
+        S[h].le = mk3(0.0f, 0.0f, 0.0f);
+    }
+    if (!__ballot(hit[0] | hit[1]))
+        return;
+    RayPair w;
+    for (int j = 0; j < L; j++) {
+        // one point light against the hits: Scene.cu:83-120 -> evaluateDirectLight :205-224
+        const LightRec light = load_uniform(&v.lights[j]);
+        v3 so[2], sd[2];
+        float sb[2], ss[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            cast[h] = false;
+            so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+            sb[h] = kInf; ss[h] = -1.0f;
+            if (hit[h]) {
+                LightSample ls = sample_point_light(S[h].hit(), v.models[S[h].model], S[h].wo_y, light);
+                cast[h] = ls.cast;
+                so[h] = ls.sr.o; sd[h] = ls.sr.d;
+                S[h].thr = fmaxf(ls.thr, 0.0f);              // Scene.cu:227 rhs
+                S[h].contrib = ls.contrib;
+                if (A.occlusion) {
+                    float m = 1e-4f * (fabsf(S[h].thr) + fabsf(so[h].x) + fabsf(so[h].y) + fabsf(so[h].z)) + 1e-6f;
+                    sb[h] = fminf(kInf, S[h].thr + m);
+                    ss[h] = S[h].thr - m;
+                }
+            }
+        }
+        const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+        if (!(c0 | c1))
+            continue;                                        // nobody casts towards this light
+        n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+        pair_set(w, so, sd, sb, ss, cast, E);
+        S[0].save(st);
+        S[1].save(st + State::kSlots * kBlock);
+        asm volatile("" ::: "memory");
+        traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
+        asm volatile("" ::: "memory");
+        S[0].load(st);
+        S[1].load(st + State::kSlots * kBlock);
+        // Scene.cu:225-241: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
+        // (H3: `lightidx == idx` restated as never true for point lights)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (!cast[h])
+                continue;
+            const float best = h ? w.best.y : w.best.x;
+            const int32_t sid = h ? w.idy : w.idx;
+            bool blocked = false;
+            if (scene_ishit(best) && sid >= 0) {
+                Ray sr;
+                sr.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+                sr.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+                v3 hp = sid < v.n_tris ? ray_pos(sr, best)
+                                       : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
+                blocked = length(sub(hp, sr.o)) < S[h].thr;
+            }
+            if (!blocked)                                    // res += ... in light order (Scene.cu:120)
+                S[h].le = add(S[h].le, S[h].contrib);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        if (hit[h]) {
+            // PathTracer.cu:73 with beta = 1, res = 0
+            v3 res = add(mk3(0.0f, 0.0f, 0.0f), mul(mk3(1.0f, 1.0f, 1.0f), S[h].le));
+            A.b.f[0][idx[h]] = res.x; A.b.f[1][idx[h]] = res.y; A.b.f[2][idx[h]] = res.z;
+        }
+    if (lane == 0 && n_shadow)
+        atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+}
+
+template <bool CULL, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_shadow(const BatchArgs A, uint32_t *__restrict__ work,
+                                                          uint32_t *__restrict__ work_next, int dynamic)
+{
+    __shared__ uint32_t s_chunk;
+    __shared__ float s_stash[2 * RayState<true>::kSlots][kBlock];
+    float *st = &s_stash[0][threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    const ChunkFeedback none{};
+    run_chunks<CULL>(
+        n_chunks * A.n_samples, none, 0u, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, n_chunks, lane, st); },
+        [&](uint32_t) {});
+}
+
+// kernel.cu:65-66,75,77 for the S samples of a batch, in sample order; cnt0 = samples
+// accumulated before the batch.  A miss contributes res = 0 (PathTracer.cu:64).
+__global__ void k_accum(SampleBatch b, float4 *__restrict__ fb, uint32_t n, uint32_t n_samples,
+                        int cnt0)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n)
+        return;
+    float4 prev = fb[p];
+    for (uint32_t s = 0; s < n_samples; s++) {
+        const size_t i = (size_t)s * b.stride + p;
+        const bool hit = __float_as_int(b.f[7][i]) >= 0;
+        const float rx = hit ? b.f[0][i] : 0.0f, ry = hit ? b.f[1][i] : 0.0f, rz = hit ? b.f[2][i] : 0.0f;
+        const int cnt = cnt0 + (int)s + 1;
+        float frac1 = 1.0f / cnt;
+        float frac2 = frac1 * (cnt - 1);
+        prev.x = frac2 * prev.x + frac1 * rx;
+        prev.y = frac2 * prev.y + frac1 * ry;
+        prev.z = frac2 * prev.z + frac1 * rz;
+        prev.w = 1.0f;
+    }
+    fb[p] = prev;
 }
 
 // ------------------------------------------------------------------ Scene::hit on a ray queue
@@ -991,6 +1296,62 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         if (d0) k_path<false, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else    k_path<false, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     }
+}
+
+static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, const SampleBatch &b, Ctl *ctl)
+{
+    BatchArgs A{};
+    A.v = v;
+    A.T = trav_args(v);
+    A.n = n; A.n_samples = n_samples;
+    A.b = b;
+    A.occlusion = v.n_spheres == 0;
+    A.ctl = ctl;
+    return A;
+}
+
+void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
+                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
+                    uint32_t *work_next, const ChunkFeedback *fb)
+{
+    if (n == 0 || n_samples == 0)
+        return;
+    BatchArgs A = batch_args(v, n, n_samples, b, ctl);
+    const int dynamic = v.cull && v.tree.top >= 3;
+    if (fb) A.fb = *fb;
+    // The chain of a step runs through this kernel (sample after sample per chunk), so heavy
+    // chunks go to whole blocks early: cooperative form from 2x the mean cost.
+    A.heavy_x4 = 8u;
+    const uint32_t g = grid_for_chunks(n, max_blocks * 4);
+    if (v.cull) k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    else        k_primary<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+}
+
+void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
+                   const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
+                   uint32_t *work_next)
+{
+    if (n == 0 || n_samples == 0)
+        return;
+    BatchArgs A = batch_args(v, n, n_samples, b, ctl);
+    const int dynamic = v.cull && v.tree.top >= 3;
+    // waves per SIMD: as launch_path
+    const int waves = !v.cull ? 2 : v.n_tris >= 200000 ? 4 : (dynamic ? 2 : 3);
+    const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
+    const unsigned long long units = (unsigned long long)n_chunks * n_samples;
+    const uint32_t g = (uint32_t)std::min<unsigned long long>(
+        std::max<unsigned long long>((units + 3) / 4, 1ull), (unsigned long long)std::max(max_blocks, 1) * waves);
+    if (!v.cull)         k_shadow<false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    else if (waves == 4) k_shadow<true, 4><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    else if (waves == 3) k_shadow<true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    else                 k_shadow<true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+}
+
+void launch_accum(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
+                  const SampleBatch &b, int cnt0)
+{
+    if (n && n_samples)
+        k_accum<<<(n + 255) / 256, 256, 0, s>>>(b, v.fb, n, n_samples, cnt0);
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

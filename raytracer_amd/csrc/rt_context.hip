@@ -560,8 +560,9 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
     hipStream_t s0 = c->stream;
-    if (max_depth == 0) {
-        // Depth 0: primary hits of a batch of samples on one stream, their shadow rays and
+    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3) {
+        // Depth 0 over a deep tree (a shallow one has no costly chunks to wait for, and the
+        // single path kernel moves fewer bytes): primary hits of a batch of samples on one stream, their shadow rays and
         // the accumulation on a second one, a batch behind (rt_kernels.hip, "depth 0 in
         // three kernels").  Two record buffers alternate; a buffer is refilled only after
         // its shadow pass has finished.

@@ -1058,8 +1058,8 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
 }
 
-template <bool CULL, int WAVES>
-__global__ __launch_bounds__(kBlock, WAVES) void k_shadow(const BatchArgs A, uint32_t *__restrict__ work,
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_t *__restrict__ work,
                                                           uint32_t *__restrict__ work_next, int dynamic)
 {
     __shared__ uint32_t s_chunk;
@@ -1319,9 +1319,13 @@ void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samp
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
     const int dynamic = v.cull && v.tree.top >= 3;
     if (fb) A.fb = *fb;
-    // The chain of a step runs through this kernel (sample after sample per chunk), so heavy
-    // chunks go to whole blocks early: cooperative form from 2x the mean cost.
-    A.heavy_x4 = 8u;
+    // The chain of a step runs through this kernel (sample after sample per chunk).  Sharing
+    // a chunk among four waves shortens the chain but costs throughput: from 4x the mean
+    // cost when the launch has few chunks per resident wave, from 8x otherwise (measured on
+    // whole frames and 1/8 partitions of C3 and C4).
+    const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
+    const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * 4u * (kBlock / 64);
+    A.heavy_x4 = n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
     const uint32_t g = grid_for_chunks(n, max_blocks * 4);
     if (v.cull) k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     else        k_primary<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
@@ -1335,16 +1339,12 @@ void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_sampl
         return;
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
     const int dynamic = v.cull && v.tree.top >= 3;
-    // waves per SIMD: as launch_path
-    const int waves = !v.cull ? 2 : v.n_tris >= 200000 ? 4 : (dynamic ? 2 : 3);
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
     const unsigned long long units = (unsigned long long)n_chunks * n_samples;
     const uint32_t g = (uint32_t)std::min<unsigned long long>(
-        std::max<unsigned long long>((units + 3) / 4, 1ull), (unsigned long long)std::max(max_blocks, 1) * waves);
-    if (!v.cull)         k_shadow<false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-    else if (waves == 4) k_shadow<true, 4><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-    else if (waves == 3) k_shadow<true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-    else                 k_shadow<true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        std::max<unsigned long long>((units + 3) / 4, 1ull), (unsigned long long)std::max(max_blocks, 1) * 4);
+    if (v.cull) k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    else        k_shadow<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
 }
 
 void launch_accum(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,

@@ -15,14 +15,16 @@ configuration and the one the metric's "primary+shadow" wording describes (69 45
 triangles, 3 lights with shadow rays, 64 spp).  `--config c2` runs configs[1] (Cornell
 box, 36 triangles, 16 spp), whose whole step is a few milliseconds.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, k_path (the whole
-path of a pixel-sample in one launch: ray generation, closest hit, shadow rays, shading,
-accumulate): algorithmic bytes per launch / its mean HIP-event duration (events on the
-stream the kernel runs on), against the 8 TB/s HBM peak.  Unit = one pixel-sample.
-Algorithmic bytes per unit ("Measurement"): 52 B = framebuffer texel read +
-write (32), RNG counter read + write (8), pixel-map entry (4), id + t buffers (8); plus
-one pass over the scene records per launch (64 B triangle record + 32 B of box tree per
-triangle, 132 B per sphere).  Rays, hits and shadow rays never touch HBM.  The figure
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: over a deep tree
+k_shadow (lights and shadow rays of a whole batch of samples; the camera rays' closest
+hits come from k_primary a batch ahead, `primary_kernel` in the line), over a shallow
+one k_path (the whole path of a pixel-sample in one launch).  Algorithmic bytes per
+launch / its mean HIP-event duration (events on the stream the kernel runs on), against
+the 8 TB/s HBM peak.  Unit = one pixel-sample.  Algorithmic bytes per unit (DESIGN.md,
+"Measurement"): k_shadow 44 B = 32-byte hit record read + 12 bytes of radiance written;
+k_path 52 B = framebuffer texel read + write (32), RNG counter read + write (8),
+pixel-map entry (4), id + t buffers (8); plus one pass over the scene records per launch
+(64 B triangle record + 32 B of box tree per triangle, 132 B per sphere).  The figure
 SURVEY 8(d) defined for a plain scan (every ray streams every triangle, one fetch shared
 by 256 rays) is reported next to it as `scan_equivalent`: it is what a scan would have
 had to move to produce the same result in the same time.  `cpu_baseline` is the CPU
@@ -47,6 +49,7 @@ SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
 RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out per ray
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
+SHADOW_UNIT_BYTES = 44.0     # k_shadow: 32 B hit record read + 12 B radiance written per pixel-sample
 
 
 def parse():
@@ -65,10 +68,10 @@ def parse():
 
 def measured_traffic(cfg_name, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic_k_path.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
+    (profiles/r01_traffic.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
     None if there is no profile for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_k_path.json")
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -77,16 +80,20 @@ def measured_traffic(cfg_name, kernel):
         return None
 
 
-def measured_counter(cfg_name, counter):
-    """Per-launch value of an SQ counter of k_path from the committed PMC summary
-    (profiles/r01_<cfg>_pmc_sq.txt, written by tools/pmc_summary.py).  None if absent."""
+def measured_counter(cfg_name, kernel, counter):
+    """Per-launch value of an SQ counter of `kernel` from the committed PMC summary
+    (profiles/r01_<cfg>_pmc_sq.txt, written by tools/pmc_summary.py: one "== kernel" section
+    per kernel).  None if absent."""
     path = os.path.join(ROOT, "profiles", f"r01_{cfg_name}_pmc_sq.txt")
     try:
+        section = None
         for line in open(path):
             f = line.split()
-            if f and f[0] == counter:
+            if f and f[0] == "==":
+                section = f[1]
+            elif f and section == kernel and f[0] == counter:
                 return float(f[f.index("launch") + 1])
-    except (OSError, ValueError):
+    except (OSError, ValueError, IndexError):
         pass
     return None
 
@@ -184,18 +191,23 @@ def main():
     if rank == 0:
         sc = cfg.scene
         n_tri, n_sph = sc.n_tris, sc.n_quads
-        # dominant (only) kernel of the step: k_path.  Unit of a launch = pixel-samples.
+        # dominant kernel of the step: k_shadow (depth-0 pipeline over a deep tree: shadow rays
+        # of a whole batch of samples) or k_path (everything of one sample).  Unit of a launch
+        # = pixel-samples.
+        pipeline = st.primary_launches > 0
+        kernel = "k_shadow" if pipeline else "k_path"
+        unit_bytes = SHADOW_UNIT_BYTES if pipeline else PIXEL_SAMPLE_BYTES
         rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
         launches = max(1, st.path_launches)
         k_ms = st.path_ms / launches
         units_per_launch = float(st.samples) / launches
-        rays_per_launch = rays_k / launches
-        bytes_per_launch = (PIXEL_SAMPLE_BYTES * units_per_launch + n_tri * TRI_REC_BYTES
+        rays_per_launch = (float(st.shadow_rays) if pipeline else rays_k) / launches
+        bytes_per_launch = (unit_bytes * units_per_launch + n_tri * TRI_REC_BYTES
                             + n_sph * SPH_BYTES)
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         # what a scan would have had to move for the same result in the same time
         scan_per_ray = (n_tri * TRI_BYTES + n_sph * SPH_BYTES) / RAYS_PER_FETCH + RAY_IO_BYTES
-        scan_gbs = scan_per_ray * rays_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        scan_gbs = scan_per_ray * (rays_total / a.steps) / (dt / a.steps) / 1e9 if dt > 0 else 0.0
         tests = rays_k * (n_tri + n_sph)
         out = {
             "metric": "Mrays/sec (primary+shadow) at 1080p",
@@ -217,13 +229,13 @@ def main():
                        "rays_per_step": rays_total / a.steps},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(cfg.name, "k_path"),
-                         "kernel": "k_path", "avg_launch_ms": k_ms,
+                         "traffic": measured_traffic(cfg.name, kernel),
+                         "kernel": kernel, "avg_launch_ms": k_ms,
                          "launches_timed": int(launches),
                          "bytes_per_launch": bytes_per_launch,
                          "pixel_samples_per_launch": units_per_launch,
                          "rays_per_launch": rays_per_launch,
-                         "concurrent_streams": int(st.streams),
+                         "concurrent_streams": 2 if pipeline else int(st.streams),
                          "note": "the path is bound by VALU issue and scalar-load latency of the "
                                  "tree traversal, not by HBM (DESIGN.md); HBM fraction reported "
                                  "as asked"},
@@ -236,15 +248,29 @@ def main():
         # committed SQ_INSTS_VALU pass (same command, profiles/), the duration is live; a
         # wave64 VALU instruction occupies its SIMD for 4 cycles, and the streams' launches
         # share the chip.
-        valu = measured_counter(cfg.name, "SQ_INSTS_VALU")
+        if pipeline:
+            out["primary_kernel"] = {"kernel": "k_primary", "launches_timed": int(st.primary_launches),
+                                     "avg_launch_ms": st.primary_ms / max(1, st.primary_launches),
+                                     "note": "closest hit of the camera rays, sample after sample per "
+                                             "chunk; runs a batch ahead of k_shadow on its own stream"}
+        valu = measured_counter(cfg.name, kernel, "SQ_INSTS_VALU")
         if valu and k_ms > 0:
             prop = torch.cuda.get_device_properties(dev)
             simds = prop.multi_processor_count * 4
             clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-            share = max(1, int(st.streams))
-            out["valu_issue"] = {"insts_per_launch": valu, "source": f"profiles/r01_{cfg.name}_pmc_sq.txt",
-                                 "simds": simds, "clock_hz": clk_hz,
-                                 "frac_of_issue_slots": valu * 4.0 / (k_ms * 1e-3 * simds * clk_hz / share)}
+            if pipeline:
+                # k_primary and k_shadow overlap on two streams: price both kernels'
+                # instructions of one batch against the wall time of one batch
+                valu_p = measured_counter(cfg.name, "k_primary", "SQ_INSTS_VALU") or 0.0
+                batch_s = dt / max(1.0, float(launches))
+                frac = (valu + valu_p) * 4.0 / (batch_s * simds * clk_hz)
+                insts = valu + valu_p
+            else:
+                share = max(1, int(st.streams))
+                frac = valu * 4.0 / (k_ms * 1e-3 * simds * clk_hz / share)
+                insts = valu
+            out["valu_issue"] = {"insts_per_launch": insts, "source": f"profiles/r01_{cfg.name}_pmc_sq.txt",
+                                 "simds": simds, "clock_hz": clk_hz, "frac_of_issue_slots": frac}
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (1600, 900),
                                                          "c3": (192, 108), "c4": (32, 18),

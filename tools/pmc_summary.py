@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
-"""Sum every counter of the given rocprofv3 counter_collection.csv files per kernel (short
-name) and print one line per (kernel, counter): total and per launch.
+"""Sum every counter of the given rocprofv3 counter_collection.csv files for the kernels whose
+name contains one of the given substrings; prints a "== kernel" section per substring with
+one line per counter: total and per launch.
 
-  python tools/pmc_summary.py <kernel substring> file.csv [file.csv ...]"""
+  python tools/pmc_summary.py <kernel[,kernel...]> file.csv [file.csv ...]"""
 import collections
 import csv
 import sys
 
 
 def main():
-    want = sys.argv[1]
-    for path in sys.argv[2:]:
+    for want in sys.argv[1].split(","):
         tot = collections.defaultdict(float)
         disp = collections.defaultdict(set)
-        for r in csv.DictReader(open(path)):
-            if want not in r["Kernel_Name"]:
-                continue
-            tot[r["Counter_Name"]] += float(r["Counter_Value"])
-            disp[r["Counter_Name"]].add(r["Dispatch_Id"])
-        print(path)
+        for path in sys.argv[2:]:
+            for r in csv.DictReader(open(path)):
+                if want not in r["Kernel_Name"]:
+                    continue
+                tot[r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[r["Counter_Name"]].add(r["Dispatch_Id"])
+        if not tot:
+            continue
+        print("== %s" % want)
         for k in sorted(tot):
             n = max(len(disp[k]), 1)
             print("  %-28s launches %4d  total %16.0f  per launch %14.0f" % (k, n, tot[k], tot[k] / n))

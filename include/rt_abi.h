@@ -41,8 +41,9 @@ typedef struct rt_context rt_context;
  * (Scene/Scene.cu:13-41): the model_size[0] standalone Triangle models, then each
  * Mesh's meshTable.  Models are numbered triangles, meshes, quadrics -- the order
  * initializeScene walks material_type[] / Material[] (Scene/Scene.cu:143-149).
- * Directional / triangle / environment lights are outside the hot path
- * (SURVEY.md section 8(f) N3): light_size[1..3] must be 0. */
+ * Point and directional lights (the delta lights, Scene.cu:93-102) are supported;
+ * triangle and environment lights (the MIS branch, Scene.cu:242-284) are outside the hot
+ * path: light_size[2..3] have no fields here. */
 typedef struct rt_scene_desc {
     int32_t n_tri_models;          /* model_size[0]                               */
     int32_t n_meshes;              /* model_size[1]                               */
@@ -61,6 +62,10 @@ typedef struct rt_scene_desc {
     int32_t n_point_lights;        /* light_size[0]                               */
     const float *pl_pos;           /* [n_point_lights][3] PointLight::pos (Light.cuh:49) */
     const float *pl_illum;         /* [n_point_lights][3] PointLight::illum       */
+    int32_t n_dir_lights;          /* light_size[1]                               */
+    const float *dl_dir;           /* [n_dir_lights][3] DirectionalLight(direction, ..) argument;
+                                      normalised as its constructor does (Light.cu:21) */
+    const float *dl_illum;         /* [n_dir_lights][3] DirectionalLight::illum (Light.cuh:57) */
 } rt_scene_desc;
 
 /* Camera(pos, lookat, fov, near, far, int2 res, up)          (Camera/Camera.cuh:11).

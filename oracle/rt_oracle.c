@@ -513,18 +513,28 @@ static f3 rec_sample_f(const orc_scene *s, const rec_t *rec, f3 wo, f3 *wi, floa
 /* ---------------------------------------------------------------- lights */
 static int is_black(f3 x) { return length3(x) < 0.001f; }           /* Scene.cu:3-5 */
 
-/* Scene/Scene.cu:205-251 evaluateDirectLight, delta-light (point) path, with
- * PointLight::lightIllumi (Light/Light.cu:7-14) inlined.  rec is by value. */
-static f3 eval_direct_point(const orc_scene *s, int j, rec_t rec, orc_counts *cnt)
+/* Scene/Scene.cu:205-251 evaluateDirectLight, delta-light path (isDelta = true), with
+ * PointLight::lightIllumi (Light/Light.cu:7-14) or DirectionalLight::lightIllumi
+ * (Light/Light.cu:21-33) inlined.  type 0 = point light j, 1 = directional light j.
+ * rec is by value. */
+static f3 eval_direct_delta(const orc_scene *s, int type, int j, rec_t rec, orc_counts *cnt)
 {
-    const float *lp = s->pl_pos + 3 * (size_t)j, *li = s->pl_illum + 3 * (size_t)j;
-    f3 lpos_ = mk3(lp[0], lp[1], lp[2]), illum = mk3(li[0], li[1], li[2]);
-
-    /* lightIllumi */
-    ray_t r = mk_ray(lpos_, sub3(rec.pos, lpos_));                  /* Light.cu:9 */
-    rec.pdf_light = 1.0f;
-    f3 dd = sub3(rec.pos, lpos_);
-    f3 color = div3s(illum, fmaxf(0.001f, dot3(dd, dd)));           /* Light.cu:13 */
+    ray_t r;
+    f3 color;
+    if (type == 0) {
+        const float *lp = s->pl_pos + 3 * (size_t)j, *li = s->pl_illum + 3 * (size_t)j;
+        f3 lpos_ = mk3(lp[0], lp[1], lp[2]), illum = mk3(li[0], li[1], li[2]);
+        r = mk_ray(lpos_, sub3(rec.pos, lpos_));                    /* Light.cu:9 */
+        rec.pdf_light = 1.0f;
+        f3 dd = sub3(rec.pos, lpos_);
+        color = div3s(illum, fmaxf(0.001f, dot3(dd, dd)));          /* Light.cu:13 */
+    } else {
+        const float *ld = s->dl_dir + 3 * (size_t)j, *li = s->dl_illum + 3 * (size_t)j;
+        f3 dir = normalize3(mk3(ld[0], ld[1], ld[2]));              /* Light.cu:21: dir(normalize(direction)) */
+        r = mk_ray(sub3(rec.pos, scale3(dir, 10000.0f)), dir);      /* Light.cu:25 */
+        rec.pdf_light = 1.0f;
+        color = mk3(li[0], li[1], li[2]);                           /* Light.cu:27 */
+    }
 
     f3 lpos = r.o;                                                  /* Scene.cu:213 */
     rec_t light_rec;
@@ -627,14 +637,19 @@ static void rng_uniform4(rng_t *g, float out[4])
 }
 
 /* Scene/Scene.cu:69-124 sampleAllLight: one curand_uniform4 per light (:87),
- * point lights only in scope. */
+ * light types in enum order; point and directional lights in scope. */
 static f3 sample_all_light(const orc_scene *s, const rec_t *rec, rng_t *g, orc_counts *cnt)
 {
     f3 res = mk3(0.0f, 0.0f, 0.0f);
-    for (int j = 0; j < s->n_point_lights; j++) {
+    for (int j = 0; j < s->n_point_lights; j++) {           /* light::POINT_LIGHT */
         float tmp[4];
         rng_uniform4(g, tmp);
-        res = add3(res, eval_direct_point(s, j, *rec, cnt));
+        res = add3(res, eval_direct_delta(s, 0, j, *rec, cnt));
+    }
+    for (int j = 0; j < s->n_dir_lights; j++) {             /* light::DIR_LIGHT */
+        float tmp[4];
+        rng_uniform4(g, tmp);
+        res = add3(res, eval_direct_delta(s, 1, j, *rec, cnt));
     }
     return res;
 }

@@ -58,6 +58,9 @@ typedef struct orc_scene {
     int32_t n_point_lights;   /* light_size[0] */
     const float *pl_pos;      /* [n_point_lights][3] */
     const float *pl_illum;    /* [n_point_lights][3] */
+    int32_t n_dir_lights;     /* light_size[1] */
+    const float *dl_dir;      /* [n_dir_lights][3] DirectionalLight constructor argument */
+    const float *dl_illum;    /* [n_dir_lights][3] */
 } orc_scene;
 
 /* The 7 constructor arguments of Camera (reference Camera/Camera.cuh:11). */

@@ -353,8 +353,9 @@ __device__ __forceinline__ void finalize_path(const DevView &v, uint32_t p, v3 r
     v.fb[p] = out;
 }
 
-// One point light against one hit: PointLight::lightIllumi (Light/Light.cu:7-14)
-// and Scene::evaluateDirectLight up to the shadow-ray test (Scene.cu:212-224).
+// One delta light against one hit: PointLight::lightIllumi (Light/Light.cu:7-14) or
+// DirectionalLight::lightIllumi (Light/Light.cu:21-33), then Scene::evaluateDirectLight up
+// to the shadow-ray test (Scene.cu:212-224).  L is wave-uniform, so the type branch is too.
 // wo_y = dot(-r.dir, normal): all Material::f reads of the outgoing direction (Object.cu:107-110,
 // material.cu:52-57).
 struct LightSample { Ray sr; v3 contrib; float thr; bool cast; };
@@ -363,9 +364,16 @@ __device__ __forceinline__ LightSample sample_point_light(const Hit &h, const Mo
 {
     LightSample s;
     v3 lp = mk3(L.pos[0], L.pos[1], L.pos[2]), illum = mk3(L.illum[0], L.illum[1], L.illum[2]);
-    Ray wi = make_ray(lp, sub(h.pos, lp));                                  // Light.cu:9
-    v3 dd = sub(h.pos, lp);
-    v3 color = divs(illum, fmaxf(0.001f, dot(dd, dd)));                     // Light.cu:13
+    Ray wi;
+    v3 color;
+    if (L.type == kLightPoint) {
+        wi = make_ray(lp, sub(h.pos, lp));                                  // Light.cu:9
+        v3 dd = sub(h.pos, lp);
+        color = divs(illum, fmaxf(0.001f, dot(dd, dd)));                    // Light.cu:13
+    } else {
+        wi = make_ray(sub(h.pos, scale(lp, 10000.0f)), lp);                 // Light.cu:25
+        color = illum;                                                      // Light.cu:27
+    }
     v3 lpos = wi.o;                                                         // Scene.cu:213
     s.sr = spawn_ray(h, neg(wi.d));                                         // Scene.cu:218
     v3 f = scale(rec_f_y(h, M, wo_y, s.sr.d), fabsf(dot(h.normal, s.sr.d)));   // Scene.cu:222

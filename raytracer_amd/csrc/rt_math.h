@@ -208,7 +208,11 @@ struct SphereRec {
     int32_t type;       // quadraticType; only Sphere (0) intersects
 };
 
-struct LightRec { float pos[3]; float illum[3]; };
+// Delta lights in Scene::sampleAllLight order (Scene.cu:83-102): point lights, then
+// directional ones.  type 0: pos = PointLight::pos; type 1: pos = DirectionalLight::dir,
+// normalised at upload as its constructor does (Light.cu:21).
+struct LightRec { float pos[3]; float illum[3]; int32_t type; int32_t pad; };
+constexpr int kLightPoint = 0, kLightDirectional = 1;
 
 // Camera after its constructor (Camera/Camera.cu:4-14); pers/raster2world are dead.
 struct CameraRec {

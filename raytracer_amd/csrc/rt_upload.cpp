@@ -335,6 +335,9 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
     if (d->n_point_lights > 0 && (!d->pl_pos || !d->pl_illum)) {
         err = "point-light arrays are NULL"; return RT_ERR_INVALID;
     }
+    if (d->n_dir_lights < 0 || (d->n_dir_lights > 0 && (!d->dl_dir || !d->dl_illum))) {
+        err = "directional-light arrays are NULL or their count negative"; return RT_ERR_INVALID;
+    }
     // traversal order: standalone triangles, then mesh tables back to back
     long long cursor = d->n_tri_models;
     for (int j = 0; j < d->n_meshes; j++) {
@@ -389,10 +392,19 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
     build_tree(out);
     if (out.top >= kMaxLevels) { err = "too many triangles for the traversal tree"; return RT_ERR_UNSUPPORTED; }
 
-    out.lights.resize((size_t)d->n_point_lights);
+    out.lights.assign((size_t)d->n_point_lights + (size_t)d->n_dir_lights, LightRec{});
     for (int j = 0; j < d->n_point_lights; j++) {
         std::memcpy(out.lights[j].pos, d->pl_pos + 3 * (size_t)j, 3 * sizeof(float));
         std::memcpy(out.lights[j].illum, d->pl_illum + 3 * (size_t)j, 3 * sizeof(float));
+        out.lights[j].type = kLightPoint;
+    }
+    for (int j = 0; j < d->n_dir_lights; j++) {
+        LightRec &L = out.lights[(size_t)d->n_point_lights + j];
+        const float *a = d->dl_dir + 3 * (size_t)j;
+        v3 dir = normalize(mk3(a[0], a[1], a[2]));            // Light.cu:21: dir(normalize(direction))
+        L.pos[0] = dir.x; L.pos[1] = dir.y; L.pos[2] = dir.z;
+        std::memcpy(L.illum, d->dl_illum + 3 * (size_t)j, 3 * sizeof(float));
+        L.type = kLightDirectional;
     }
     return RT_OK;
 }

@@ -89,7 +89,7 @@ class SceneDesc(C.Structure):
                 ("mesh_first", _IP), ("mesh_count", _IP), ("model_xf", _FP),
                 ("model_mat_type", _IP), ("model_color", _FP), ("quad_coeff", _FP),
                 ("quad_type", _IP), ("n_point_lights", C.c_int32), ("pl_pos", _FP),
-                ("pl_illum", _FP)]
+                ("pl_illum", _FP), ("n_dir_lights", C.c_int32), ("dl_dir", _FP), ("dl_illum", _FP)]
 
 
 @dataclass
@@ -108,6 +108,8 @@ class SceneData:
     quad_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
     pl_pos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     pl_illum: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    dl_dir: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    dl_illum: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
 
     @property
     def n_tris(self):
@@ -131,7 +133,8 @@ class SceneData:
 
     @property
     def n_lights(self):
-        return int(self.pl_pos.shape[0])
+        """Delta lights: point lights, then directional ones (Scene.cu:83-102 order)."""
+        return int(self.pl_pos.shape[0]) + int(np.asarray(self.dl_dir).reshape(-1, 3).shape[0])
 
     def normalise(self):
         n = self.tri_pos.shape[0] if self.tri_pos.ndim == 3 else np.asarray(self.tri_pos).size // 9
@@ -148,7 +151,10 @@ class SceneData:
         self.model_color = _f32(self.model_color, (nm, 3))
         self.pl_pos = _f32(self.pl_pos, (-1, 3))
         self.pl_illum = _f32(self.pl_illum, (-1, 3))
+        self.dl_dir = _f32(self.dl_dir, (-1, 3))
+        self.dl_illum = _f32(self.dl_illum, (-1, 3))
         assert self.pl_pos.shape == self.pl_illum.shape
+        assert self.dl_dir.shape == self.dl_illum.shape
         assert self.quad_type.shape[0] == self.quad_coeff.shape[0]
         assert int(self.mesh_count.sum()) + self.n_tri_models == n
         return self
@@ -166,8 +172,10 @@ class SceneData:
         d.model_xf, d.model_mat_type = fp(self.model_xf), ip(self.model_mat_type)
         d.model_color = fp(self.model_color)
         d.quad_coeff, d.quad_type = fp(self.quad_coeff), ip(self.quad_type)
-        d.n_point_lights = self.n_lights
+        d.n_point_lights = int(self.pl_pos.shape[0])
         d.pl_pos, d.pl_illum = fp(self.pl_pos), fp(self.pl_illum)
+        d.n_dir_lights = int(self.dl_dir.shape[0])
+        d.dl_dir, d.dl_illum = fp(self.dl_dir), fp(self.dl_illum)
         return d
 
 
@@ -180,6 +188,7 @@ class SceneBuilder:
         self._meshes = []    # (pos[n,3,3], nrm[n,3,3], xf, color)
         self._quads = []     # (coeff, type, xf, color)
         self._lights = []
+        self._dir_lights = []
 
     def add_triangle(self, pos, nrm, xf=None, color=(0.7, 0.7, 0.7)):
         self._tris.append((_f32(pos, (3, 3)), _f32(nrm, (3, 3)),
@@ -200,6 +209,11 @@ class SceneBuilder:
 
     def add_point_light(self, pos, illum):
         self._lights.append((pos, illum))
+        return self
+
+    def add_directional_light(self, direction, illum):
+        """DirectionalLight(direction, color) (Light/Light.cuh:57)."""
+        self._dir_lights.append((direction, illum))
         return self
 
     def build(self) -> SceneData:
@@ -229,4 +243,6 @@ class SceneBuilder:
         s.quad_type = np.array([q[1] for q in self._quads], np.int32)
         s.pl_pos = np.array([l[0] for l in self._lights], np.float32).reshape(-1, 3)
         s.pl_illum = np.array([l[1] for l in self._lights], np.float32).reshape(-1, 3)
+        s.dl_dir = np.array([l[0] for l in self._dir_lights], np.float32).reshape(-1, 3)
+        s.dl_illum = np.array([l[1] for l in self._dir_lights], np.float32).reshape(-1, 3)
         return s.normalise()

@@ -318,4 +318,15 @@ def mixed_test_scene(seed=7):
     return b.build(), rng
 
 
+def sun_test_scene(seed=7):
+    """mixed_test_scene with one point light swapped for two directional lights (delta
+    lights of Scene.cu:97-102): a low sun casting long shadows and a weak fill from above."""
+    scene, rng = mixed_test_scene(seed)
+    scene.pl_pos = scene.pl_pos[:2].copy()
+    scene.pl_illum = scene.pl_illum[:2].copy()
+    scene.dl_dir = np.float32([[0.6, -0.35, -0.7], [-0.1, -2.0, 0.3]])
+    scene.dl_illum = np.float32([[2.2, 2.0, 1.7], [0.25, 0.3, 0.4]])
+    return scene.normalise(), rng
+
+
 CONFIGS = {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}

@@ -36,11 +36,13 @@ CASES = {
     "c4": (("c4", dict(lon=20, lat=16, ground=(6, 1))), 128, 72, (40, 16, 88, 64), [(1, 0)]),
     "c5": (("c5", dict(nx=12, nz=10)), 64, 36, (16, 8, 48, 28), [(1, 0)]),
     "mixed": (("mixed", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 5)]),
+    "sun": (("sun", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 5)]),
 }
 
 
 SCENE_FIELDS = ["tri_pos", "tri_nrm", "tri_model", "mesh_first", "mesh_count", "model_xf",
                 "model_mat_type", "model_color", "quad_coeff", "quad_type", "pl_pos", "pl_illum"]
+OPTIONAL_SCENE_FIELDS = ["dl_dir", "dl_illum"]       # absent from fixtures written before them
 
 
 def load_case(name):
@@ -51,6 +53,9 @@ def load_case(name):
     scene.n_tri_models = int(z["scene_n_tri_models"])
     for f in SCENE_FIELDS:
         setattr(scene, f, z["scene_" + f])
+    for f in OPTIONAL_SCENE_FIELDS:
+        if "scene_" + f in z:
+            setattr(scene, f, z["scene_" + f])
     scene.normalise()
     c = json.loads(str(z["camera"]))
     cam = CameraArgs(pos=tuple(c["pos"]), lookat=tuple(c["lookat"]), fov=c["fov"], near=c["near"],
@@ -61,8 +66,8 @@ def load_case(name):
 
 def build_case(name):
     (kind, kw), w, h, crop, runs = CASES[name]
-    if kind == "mixed":
-        scene, _ = scenes.mixed_test_scene()
+    if kind in ("mixed", "sun"):
+        scene, _ = scenes.mixed_test_scene() if kind == "mixed" else scenes.sun_test_scene()
         cam = CameraArgs.for_image(w, h, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
     else:
         cfg = scenes.CONFIGS[kind](w, h, **kw)
@@ -71,7 +76,11 @@ def build_case(name):
 
 
 def main():
+    import sys
+    only = sys.argv[1:]                   # e.g. `python -m tests.golden.make_golden sun`
     for name in CASES:
+        if only and name not in only:
+            continue
         scene, cam, w, h, crop, runs = build_case(name)
         out = {}
         for spp, depth in runs:
@@ -81,7 +90,7 @@ def main():
             out[k + "_prim"] = r["prim_id"]
             out[k + "_t"] = r["t"]
             out[k + "_rays"] = np.array([r["primary"], r["shadow"], r["bounce"]], np.int64)
-        for f in SCENE_FIELDS:
+        for f in SCENE_FIELDS + OPTIONAL_SCENE_FIELDS:
             out["scene_" + f] = getattr(scene, f)
         out["scene_n_tri_models"] = np.array(scene.n_tri_models)
         out["camera"] = np.array(json.dumps(dict(pos=cam.pos, lookat=cam.lookat, fov=cam.fov,
@@ -94,6 +103,8 @@ def main():
         out["meta"] = np.array(json.dumps(meta))
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
         print(name, {k: v.shape for k, v in out.items() if k != "meta"})
+    if only:
+        return
     # RNG fixture: first 16 uniform4 draws of 4 pixel streams (H7 convention)
     pix = [0, 1, 1919, 2073599]
     u = np.array([[orc.pixel_uniform4(p, d) for d in range(16)] for p in pix], np.float32)

@@ -125,3 +125,36 @@ def test_oracle_postprocess_reference_values():
     lum = (0.299 * img[..., 0] + 0.587 * img[..., 1] + 0.114 * img[..., 2])
     w = sorted(lum[2:5, 3:6].reshape(-1), reverse=True)[4]
     assert np.isclose(0.299 * med[3, 4, 0] + 0.587 * med[3, 4, 1] + 0.114 * med[3, 4, 2], w)
+
+
+def test_directional_light_closed_form():
+    """DirectionalLight::lightIllumi (Light/Light.cu:21-33) through the delta-light branch of
+    evaluateDirectLight: an unoccluded Lambertian plate facing the light receives
+    illum * |cos| * albedo / pi (pdf_light = 1, no distance falloff); an occluder between plate
+    and light blocks it (Scene.cu:227); a light from behind the plate gives black
+    (Lambertian::f needs wi.y > 0)."""
+    def plate_scene(direction, blocker=False):
+        b = SceneBuilder()
+        b.add_triangle([(-500, -500, -100), (500, -500, -100), (0, 600, -100)], [(0, 0, 1)] * 3,
+                       None, (0.7, 0.5, 0.3))
+        if blocker:
+            b.add_triangle([(-50, -50, -50), (50, -50, -50), (0, 60, -50)], [(0, 0, 1)] * 3,
+                           None, (0.7, 0.7, 0.7))
+        b.add_directional_light(direction, (2.0, 1.0, 0.5))
+        return b.build()
+    org, d = np.float32([3.0, 2.0, 0.0]), np.float32([0.0, 0.0, -1.0])
+    rgb, t, prim = orc.trace_ray(plate_scene((0.0, 0.0, -3.0)), org, d, 0)
+    assert prim == 0 and abs(t - 100.0) < 1e-3
+    want = np.float32([2.0, 1.0, 0.5]) * np.float32([0.7, 0.5, 0.3]) * np.float32(0.318309892)
+    assert np.allclose(rgb, want, rtol=2e-6)
+    # oblique: cos = 0.8
+    rgb, _, _ = orc.trace_ray(plate_scene((0.6, 0.0, -0.8)), org, d, 0)
+    assert np.allclose(rgb, want * np.float32(0.8), rtol=1e-5)
+    # from behind the plate: Lambertian f = 0
+    rgb, _, _ = orc.trace_ray(plate_scene((0.0, 0.0, 1.0)), org, d, 0)
+    assert (rgb == 0).all()
+    # occluded (Scene.cu:227): a ray that passes beside the blocker and lands below its interior
+    rgb2, _, prim2 = orc.trace_ray(plate_scene((0.0, 0.0, -1.0), blocker=True),
+                                   np.float32([0.0, 200.0, 0.0]), np.float32([0.0, -1.98, -1.0]), 0)
+    # that ray lands at (0, 2, -100), straight below the blocker's interior: blocked
+    assert prim2 == 0 and (rgb2 == 0).all()

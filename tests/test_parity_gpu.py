@@ -213,6 +213,29 @@ def test_mixed_scene(gpu_ctx_factory, depth, spp):
     check_images(got, ref, st)
 
 
+@pytest.mark.parametrize("depth,spp", [(0, 3), (6, 2)])
+def test_directional_lights(gpu_ctx_factory, depth, spp):
+    """Point and directional lights together (the delta lights of Scene.cu:93-102), in
+    sampleAllLight's order; the directional ones cast shadow rays 10 000 units long."""
+    scene, _ = scenes.sun_test_scene()
+    assert scene.n_lights == 4 and scene.dl_dir.shape[0] == 2
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    got, ref, st = render_both(gpu_ctx_factory, scene, cam, 96, 64, spp, depth)
+    check_images(got, ref, st)
+    assert st.shadow_rays > 4000
+
+
+def test_directional_light_deep_tree(gpu_ctx_factory):
+    """The same through the depth-0 pipeline (deep tree) with only a directional light."""
+    cfg = scenes.c3(128, 72, lon=24, lat=24, ground=(8, 4))
+    cfg.scene.pl_pos = cfg.scene.pl_pos[:1].copy()
+    cfg.scene.pl_illum = cfg.scene.pl_illum[:1].copy()
+    cfg.scene.dl_dir = np.float32([[0.3, -1.0, -0.2]])
+    cfg.scene.dl_illum = np.float32([[1.5, 1.4, 1.2]])
+    got, ref, st = render_both(gpu_ctx_factory, cfg.scene, cfg.camera, 128, 72, 3, 0)
+    check_images(got, ref, st)
+
+
 def test_many_lights(gpu_ctx_factory):
     """More lights than one 64-bit shadow mask holds: exercises the multi-pass light loop."""
     cfg = scenes.c5(64, 36, nx=12, nz=10, n_light_side=9)       # 81 lights

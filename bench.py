@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 path with every rank on ONE GPU "
+                         "(gather staged through host memory); not a measurement")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=None, metavar=("W", "H"))
     return ap.parse_args()
 
@@ -130,9 +133,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    dev = local_rank if (world > 1 and a.backend == "nccl") else 0
+    cdev = "cuda" if a.backend == "nccl" else "cpu"      # where the collectives' tensors live
     torch.cuda.set_device(dev)
 
     kw = {}
@@ -150,13 +157,18 @@ def main():
     gather = None
     if world > 1:
         from raytracer_amd.dist import FrameGather
-        gather = FrameGather(cfg.width, cfg.height, world, 64, "cuda", abi.partition_pixels)
+        gather = FrameGather(cfg.width, cfg.height, world, 64, cdev, abi.partition_pixels)
+        stage = torch.zeros_like(gather.local, device="cuda") if cdev == "cpu" else None
 
     def step():
         ctx.reset()                      # a fresh frame: counters, RNG streams, framebuffer
         ctx.render(spp, 0)
         if world > 1:                    # final framebuffer gathered over xGMI (RCCL)
-            ctx.export_local_rgba(gather.local.data_ptr())
+            if stage is None:
+                ctx.export_local_rgba(gather.local.data_ptr())
+            else:
+                ctx.export_local_rgba(stage.data_ptr())
+                gather.local.copy_(stage)
             gather.gather(dist)
 
     def fence():
@@ -179,10 +191,10 @@ def main():
 
     rays_local = float(st.primary_rays + st.shadow_rays)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        rr = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        rr = torch.tensor([rays_local], dtype=torch.float64, device=cdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays_total = float(rr.item())
     else:

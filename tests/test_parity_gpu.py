@@ -322,3 +322,113 @@ def test_errors(gpu_ctx_factory):
         ctx.upload_scene(cfg.scene)
     assert e.value.code == abi.RT_ERR_UNSUPPORTED
     ctx.close()
+
+
+# ---------------------------------------------------------------- BASELINE.json's full sizes
+def _oracle_crops(cfg, crops, spp, depth=0):
+    out = []
+    for (x0, y0, cw, ch) in crops:
+        out.append(((x0, y0, cw, ch),
+                    orc.render(cfg.scene, cfg.camera, cfg.width, cfg.height, spp=spp,
+                               max_depth=depth, crop=(x0, y0, x0 + cw, y0 + ch))))
+    return out
+
+
+def _check_crops(got, refs):
+    for (x0, y0, cw, ch), ref in refs:
+        sl = (slice(y0, y0 + ch), slice(x0, x0 + cw))
+        assert np.array_equal(got["prim_id"][sl], ref["prim_id"]), (x0, y0)
+        assert np.array_equal(got["t"][sl].view(np.uint32), ref["t"].view(np.uint32)), (x0, y0)
+        assert_radiance(got["rgba"][sl], ref["rgba"])
+
+
+def test_full_size_c2(gpu_ctx_factory):
+    """C2 as BASELINE.json states it (1920x1080, 16 spp): oracle on windows of the frame."""
+    cfg = scenes.c2()
+    ctx = gpu_ctx_factory(cfg.width, cfg.height)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    ctx.render(cfg.spp, 0)
+    got = ctx.read_framebuffer()
+    crops = [(0, 0, 40, 24), (940, 520, 48, 32), (1872, 1050, 48, 30), (300, 900, 32, 32)]
+    _check_crops(got, _oracle_crops(cfg, crops, cfg.spp))
+    assert (got["prim_id"] >= 0).mean() > 0.9
+
+
+def test_full_size_c3(gpu_ctx_factory):
+    """C3 at its full size (69 451 triangles, 3 lights, 1920x1080): the depth-0 pipeline over
+    several batches against the oracle on windows at the silhouette, the ground and the sky;
+    and rendering in two calls equals rendering in one (counters and streams persist)."""
+    cfg = scenes.c3()
+    ctx = gpu_ctx_factory(cfg.width, cfg.height)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    spp = 3
+    ctx.render(spp, 0)
+    got = ctx.read_framebuffer()
+    hit = got["prim_id"] >= 0
+    ys, xs = np.nonzero(hit[:, :-1] != hit[:, 1:])          # silhouette / horizon columns
+    k = len(xs) // 2
+    crops = [(int(min(max(xs[k] - 8, 0), cfg.width - 16)), int(min(max(ys[k] - 4, 0), cfg.height - 8)), 16, 8),
+             (952, 536, 16, 8), (40, 1040, 16, 8), (900, 4, 16, 4)]
+    _check_crops(got, _oracle_crops(cfg, crops, spp))
+    ctx.reset()
+    ctx.render(2, 0)
+    ctx.render(1, 0)
+    again = ctx.read_framebuffer()
+    for key in ("rgba", "t", "prim_id"):
+        assert np.array_equal(got[key].view(np.uint32), again[key].view(np.uint32)), key
+
+
+def test_full_size_c4_rays(gpu_ctx_factory):
+    """C4's full mesh (871 414 triangles): Scene::hit with the tree equals the scan of every
+    triangle, bit for bit, on camera-like and random rays; a handful of them against the oracle."""
+    cfg = scenes.c4()
+    ctx = gpu_ctx_factory(64, 64)
+    ctx.upload_scene(cfg.scene)
+    rng = np.random.default_rng(5)
+    n = 4096
+    pos = np.asarray(cfg.camera.pos, np.float32)
+    look = np.asarray(cfg.camera.lookat, np.float32)
+    org = np.tile(pos, (n, 1)).astype(np.float32)
+    span = np.abs(cfg.scene.tri_pos).max()
+    tgt = look + rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32) * np.float32(span)
+    org[n // 2:] = rng.uniform(-1.0, 1.0, (n - n // 2, 3)).astype(np.float32) * np.float32(span)
+    d = (tgt - org).astype(np.float32)
+    ctx.set_culling(1)
+    t1, id1, h1 = ctx.scene_hit(org, d)
+    ctx.set_culling(0)
+    t0, id0, h0 = ctx.scene_hit(org, d)
+    ctx.set_culling(1)
+    assert np.array_equal(id1, id0) and np.array_equal(t1.view(np.uint32), t0.view(np.uint32))
+    assert np.array_equal(h1, h0) and 0.05 < h1.mean() < 1.0
+    pick = np.concatenate([np.nonzero(h1)[0][:12], np.nonzero(h1 == 0)[0][:4]])
+    rt, rid, rh = orc.scene_hit(cfg.scene, org[pick], d[pick])
+    assert np.array_equal(id1[pick], rid) and np.array_equal(t1[pick].view(np.uint32), rt.view(np.uint32))
+
+
+def test_full_size_c5_rays(gpu_ctx_factory):
+    """C5's 10 M-triangle mesh: tree == scan on rays from the camera and towards the lights."""
+    cfg = scenes.c5()
+    assert cfg.scene.n_tris == 10_000_000 and cfg.scene.n_lights == 64
+    ctx = gpu_ctx_factory(64, 64)
+    ctx.upload_scene(cfg.scene)
+    rng = np.random.default_rng(9)
+    n = 1024
+    pos = np.asarray(cfg.camera.pos, np.float32)
+    look = np.asarray(cfg.camera.lookat, np.float32)
+    span = np.float32(np.abs(cfg.scene.tri_pos[::997]).max())
+    org = np.tile(pos, (n, 1)).astype(np.float32)
+    tgt = look + rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32) * span
+    # second half: from points just above the surface towards the lights (shadow-ray like)
+    v = cfg.scene.tri_pos[rng.integers(0, cfg.scene.n_tris, n // 2), 0, :]
+    org[n // 2:] = v + np.float32([0.0, 0.5, 0.0])
+    tgt[n // 2:] = cfg.scene.pl_pos[rng.integers(0, 64, n // 2)]
+    d = (tgt - org).astype(np.float32)
+    ctx.set_culling(1)
+    t1, id1, h1 = ctx.scene_hit(org, d)
+    ctx.set_culling(0)
+    t0, id0, h0 = ctx.scene_hit(org, d)
+    ctx.set_culling(1)
+    assert np.array_equal(id1, id0) and np.array_equal(t1.view(np.uint32), t0.view(np.uint32))
+    assert np.array_equal(h1, h0) and h1.mean() > 0.1

@@ -192,7 +192,7 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
 // lvloff: lane l holds the first group of level l.
 // COOP: called by all four waves of the block with identical rays; s_best is the block's
 // LDS merge array (128 entries).  Every wave returns the block's common answer.
-template <bool CULL, bool COOP>
+template <bool CULL, bool COOP, bool ORDER = true>
 __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, RayPair &r,
                                          uint32_t lane, uint32_t wib,
                                          unsigned long long *s_best, uint32_t &cost)
@@ -269,10 +269,16 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                     if (take) {
                         // visit order: entry parameter of the first passing lane (a coherent
                         // wave's rays agree on it closely enough); the child index rides in
-                        // the two low mantissa bits
-                        float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                            __builtin_bit_cast(int, near), __builtin_ctzll(b)));
-                        key[j] = (__builtin_bit_cast(uint32_t, e) & ~3u) | (uint32_t)j;
+                        // the two low mantissa bits.  ORDER = false (occlusion rays: any hit
+                        // below the threshold ends the ray, so nearest-first buys nothing):
+                        // index order.
+                        if (ORDER) {
+                            float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                                __builtin_bit_cast(int, near), __builtin_ctzll(b)));
+                            key[j] = (__builtin_bit_cast(uint32_t, e) & ~3u) | (uint32_t)j;
+                        } else {
+                            key[j] = (uint32_t)j;
+                        }
                         n_pass++;
                     }
                 }
@@ -1030,7 +1036,7 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
         S[0].save(st);
         S[1].save(st + State::kSlots * kBlock);
         asm volatile("" ::: "memory");
-        traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
+        traverse<CULL, false, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
         asm volatile("" ::: "memory");
         S[0].load(st);
         S[1].load(st + State::kSlots * kBlock);

@@ -39,6 +39,7 @@ struct Lane {
     uint32_t *early[3] = {nullptr, nullptr, nullptr};
     uint8_t *flag[3] = {nullptr, nullptr, nullptr};
     FbCounts *cnt = nullptr;             // [3]
+    uint32_t *acc = nullptr;             // [chunks]
     uint32_t fb_slots = 0;
     uint32_t fb_seq = 0;                 // path launches so far (set rotation)
 };
@@ -185,6 +186,8 @@ int alloc_feedback(rt_context *c, Lane &L)
         if ((rc = dalloc(c, c->part_allocs, L.flag[s], chunks))) return rc;
         RT_HIP(c, hipMemset(L.flag[s], 0, std::max<size_t>(chunks, 1)));
     }
+    if ((rc = dalloc(c, c->part_allocs, L.acc, chunks))) return rc;
+    RT_HIP(c, hipMemset(L.acc, 0, std::max<size_t>(chunks, 1) * sizeof(uint32_t)));
     if ((rc = dalloc(c, c->part_allocs, L.cnt, 3))) return rc;
     RT_HIP(c, hipMemset(L.cnt, 0, 3 * sizeof(FbCounts)));
     L.fb_slots = (uint32_t)std::max<size_t>(chunks, 1);
@@ -322,6 +325,7 @@ ChunkFeedback next_feedback(Lane &L)
     f.cnt_r = L.cnt + r; f.heavy_r = L.heavy[r]; f.early_r = L.early[r]; f.flag_r = L.flag[r];
     f.cnt_w = L.cnt + w; f.heavy_w = L.heavy[w]; f.early_w = L.early[w]; f.flag_w = L.flag[w];
     f.cnt_z = L.cnt + z;
+    f.acc = L.acc;
     f.n_slots = L.fb_slots;
     L.fb_seq++;
     return f;

@@ -62,6 +62,7 @@ struct ChunkFeedback {
     uint32_t *early_w;
     uint8_t *flag_w;
     FbCounts *cnt_z;
+    uint32_t *acc;                       // per chunk: cost accumulator of sub-divided heavy chunks (k_primary)
     uint32_t n_slots;                    // entries of the heavy / early arrays (= chunks of the range)
 };
 

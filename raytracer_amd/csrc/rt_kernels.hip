@@ -730,8 +730,9 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
 // depends on how many chunks a launch has (launch_path).
 // The dispatch every chunked kernel here shares.  solo(chunk) runs one chunk on the calling
 // wave, coop(chunk) runs it on the whole block (cooperative form; needs feedback).
+// hm: cooperative units per heavy chunk (coop(chunk, sub), sub < hm).
 template <bool CULL, class Solo, class Coop>
-__device__ __forceinline__ void run_chunks(uint32_t n_chunks, const ChunkFeedback &fb,
+__device__ __forceinline__ void run_chunks(uint32_t hm, uint32_t n_chunks, const ChunkFeedback &fb,
                                            uint32_t heavy_x4, uint32_t *__restrict__ work,
                                            uint32_t *__restrict__ work_next, int dynamic,
                                            ChunkEnv &env, uint32_t *s_chunk, Solo solo, Coop coop)
@@ -766,9 +767,9 @@ __device__ __forceinline__ void run_chunks(uint32_t n_chunks, const ChunkFeedbac
             __syncthreads();
             const uint32_t d = *s_chunk;
             __syncthreads();
-            if (d >= n_heavy)
+            if (d >= n_heavy * hm)
                 break;
-            coop(fb.heavy_r[d]);
+            coop(fb.heavy_r[d / hm], d % hm);
         }
     }
     // phase 2, one chunk per wave at a time: first the previous launch's early chunks,
@@ -825,9 +826,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     run_chunks<CULL>(
-        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
+        1u, n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t chunk) { path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
-        [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+        [&](uint32_t chunk, uint32_t) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
 }
 
 // ------------------------------------------------------------------ depth 0 in three kernels
@@ -850,15 +851,24 @@ struct BatchArgs {
     uint32_t n_samples;              // samples in this batch
     SampleBatch b;
     uint32_t ss_log2;                // k_shadow: log2 of the samples packed into one wave
+    uint32_t heavy_split;            // k_primary: cooperative units per heavy chunk (1 or 4 quarters)
     bool occlusion;
     Ctl *ctl;
     ChunkFeedback fb;
     uint32_t heavy_x4;
 };
 
+// COOP = false: the calling wave runs the whole chunk alone.  COOP = true (heavy chunks): the
+// block's four waves share the traversals by subtree, either of the whole chunk (sub =
+// kWholeChunk) or of QUARTER `sub` of it -- 32 pixels, an 8x4 patch, in lanes 0..31; the
+// chunk's four quarters then go to four blocks, sixteen waves in all on what sits on the
+// chain of the step (samples x costliest chunk), their costs meet in fb.acc[chunk], and the
+// last one to arrive classifies the chunk for the next launch.  Quarters pay off when the
+// launch has fewer chunks than resident waves (small partitions); they cost throughput.
+constexpr uint32_t kWholeChunk = 0xffffffffu;
 template <bool CULL, bool COOP>
 __device__ __forceinline__ void primary_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t chunk,
-                                              uint32_t lane, uint32_t wib,
+                                              uint32_t sub, uint32_t lane, uint32_t wib,
                                               unsigned long long *s_best, uint32_t *s_cost)
 {
     const DevView &v = A.v;
@@ -872,8 +882,10 @@ __device__ __forceinline__ void primary_chunk(const BatchArgs &A, const ChunkEnv
     bool mine[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const uint32_t pl = chunk * kPathChunk + (uint32_t)h * 64u + lane;
-        mine[h] = pl < A.n;
+        const bool quarter = COOP && sub != kWholeChunk;
+        const uint32_t pl = quarter ? chunk * kPathChunk + sub * 32u + (lane & 31u)
+                                    : chunk * kPathChunk + (uint32_t)h * 64u + lane;
+        mine[h] = pl < A.n && (!quarter || (h == 0 && lane < 32u));
         p[h] = min(pl, A.n - 1u);
         pix[h] = v.pixmap[p[h]];
         draw[h] = v.rng_ctr[p[h]];
@@ -955,8 +967,18 @@ __device__ __forceinline__ void primary_chunk(const BatchArgs &A, const ChunkEnv
         if (wib != 0)
             return;
     }
-    if (lane == 0 && env.feedback)
-        record_cost(A.fb, env, chunk, cost);
+    if (lane == 0 && env.feedback) {
+        if (COOP && sub != kWholeChunk) {
+            // count of quarters done in the top four bits, their summed cost below
+            const uint32_t old = atomicAdd(&A.fb.acc[chunk], (cost & 0x0fffffffu) + (1u << 28));
+            if ((old >> 28) == 3u) {
+                A.fb.acc[chunk] = 0u;
+                record_cost(A.fb, env, chunk, (old & 0x0fffffffu) + cost);
+            }
+        } else {
+            record_cost(A.fb, env, chunk, cost);
+        }
+    }
 }
 
 template <bool CULL>
@@ -969,10 +991,13 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32
     const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    const uint32_t hm = A.heavy_split;
     run_chunks<CULL>(
-        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t chunk) { primary_chunk<CULL, false>(A, env, chunk, lane, wib, nullptr, nullptr); },
-        [&](uint32_t chunk) { primary_chunk<CULL, true>(A, env, chunk, lane, wib, s_best, &s_cost); });
+        hm, n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t chunk) { primary_chunk<CULL, false>(A, env, chunk, 0u, lane, wib, nullptr, nullptr); },
+        [&](uint32_t chunk, uint32_t q) {
+            primary_chunk<CULL, true>(A, env, chunk, hm > 1u ? q : kWholeChunk, lane, wib, s_best, &s_cost);
+        });
 }
 
 // One unit = 128 pixel-samples = px consecutive pixels (a compact patch of the image) x ss
@@ -1094,9 +1119,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_
     const uint32_t n_groups = (A.n + px - 1u) / px;
     const uint32_t s_groups = (A.n_samples + ss - 1u) / ss;
     run_chunks<CULL>(
-        n_groups * s_groups, none, 0u, work, work_next, dynamic, env, &s_chunk,
+        1u, n_groups * s_groups, none, 0u, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, n_groups, lane, st); },
-        [&](uint32_t) {});
+        [&](uint32_t, uint32_t) {});
 }
 
 // kernel.cu:65-66,75,77 for the S samples of a batch, in sample order; cnt0 = samples
@@ -1349,6 +1374,7 @@ void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samp
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * 4u * (kBlock / 64);
     A.heavy_x4 = n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
+    A.heavy_split = n_chunks <= slots ? 4u : 1u;
     const uint32_t g = grid_for_chunks(n, max_blocks * 4);
     if (v.cull) k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     else        k_primary<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);

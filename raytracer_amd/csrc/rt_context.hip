@@ -239,6 +239,7 @@ int setup_partition(rt_context *c)
     RT_HIP(c, hipMemset(c->shade_ctl, 0, sizeof(Ctl)));
     c->shade_seq = 0;
     c->batch_cap = 0;                    // record buffers went with part_allocs
+    c->batch[0].hard_q = c->batch[1].hard_q = nullptr;
     return RT_OK;
 }
 
@@ -247,6 +248,13 @@ int ensure_batches(rt_context *c, uint32_t cap)
 {
     if (cap <= c->batch_cap) return RT_OK;
     const size_t n = (size_t)c->n_local * cap;
+    if (!c->batch[0].hard_q) {           // one queue: k_primary launches follow each other on one stream
+        int rc = dalloc(c, c->part_allocs, c->batch[0].hard_q, (size_t)c->n_local);
+        if (rc == RT_OK) rc = dalloc(c, c->part_allocs, c->batch[0].hard_cnt, 2);
+        if (rc) return rc;
+        c->batch[1].hard_q = c->batch[0].hard_q;
+        c->batch[1].hard_cnt = c->batch[0].hard_cnt;
+    }
     for (int b = 0; b < 2; b++) {
         for (int k = 0; k < 8; k++) {
             int rc = dalloc(c, c->part_allocs, c->batch[b].f[k], n);   // outgrown ones stay until re-partition
@@ -589,7 +597,7 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             ChunkFeedback f = next_feedback(W);
             if (p0) (void)hipEventRecord(p0, sa);
             launch_primary(sa, c->v, c->n_local, S, c->batch[b], c->max_blocks, W.ctl,
-                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u], &f);
+                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u], &f, c->cnt == 0);
             W.seq++;
             if (p1) (void)hipEventRecord(p1, sa);
             RT_HIP(c, hipEventRecord(c->ev_prim_done[b], sa));

@@ -95,6 +95,8 @@ struct DevView {
 struct SampleBatch {
     float *f[8];
     uint32_t stride;                // pixels of the partition
+    uint4 *hard_q;                  // k_primary's queue of pixels whose samples flip outcome: one entry per pixel
+    uint32_t *hard_cnt;             // [0] queued, [1] taken
 };
 
 // One progressive sample of local pixels [p0, p0 + n): the whole path of every pixel
@@ -108,7 +110,7 @@ constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (t
 // Depth-0 pipeline over the whole partition (n pixels), one batch of n_samples samples.
 void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next, const ChunkFeedback *fb);
+                    uint32_t *work_next, const ChunkFeedback *fb, bool first_batch);
 void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
                    uint32_t *work_next);

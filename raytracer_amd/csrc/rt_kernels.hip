@@ -852,6 +852,9 @@ struct BatchArgs {
     SampleBatch b;
     uint32_t ss_log2;                // k_shadow: log2 of the samples packed into one wave
     uint32_t heavy_split;            // k_primary: cooperative units per heavy chunk (1 or 4 quarters)
+    uint32_t predict_hit;            // k_primary_batch: no sample yet to predict a pixel's draws from
+    uint4 *hard_q;                   // k_primary_batch -> k_primary_hard: (pixel, first open sample, its counter, -)
+    uint32_t *hard_cnt;              // [0] entries queued, [1] entries taken
     bool occlusion;
     Ctl *ctl;
     ChunkFeedback fb;
@@ -998,6 +1001,280 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32
         [&](uint32_t chunk, uint32_t q) {
             primary_chunk<CULL, true>(A, env, chunk, hm > 1u ? q : kWholeChunk, lane, wib, s_best, &s_cost);
         });
+}
+
+// k_primary, all samples of a batch at once.  The samples of a pixel are chained only through
+// the NUMBER of draws each one consumes: 2 on a miss, 2 + lights on a hit, +1 if the hit's BRDF
+// sample is usable (PathTracer.cu:77) -- and that number is almost always the one of the sample
+// before.  Two kernels:
+//   k_primary_batch  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples; 8 x 16
+//     for a full batch).  Every sample's counter is PREDICTED from its pixel's expected draws
+//     per sample (round 0: what the pixel's last sample did; round 1: what the first
+//     mispredicted one did), all are traced together, and the prediction is checked pixel by
+//     pixel: the samples up to and including the first whose draw count differs were traced
+//     from the counter the sequential order gives them and are final.  Pixels still open
+//     after two rounds flip between outcomes from sample to sample (silhouettes, ~1 % of the
+//     pixels): they go to a queue.
+//   k_primary_hard   one queued pixel per wave.  The next 8 samples can only start at the
+//     counters base + 2 a + (2 + lights) b + (3 + lights) c, a + b + c < 8 -- 120 candidates --
+//     so the wave traces ALL of them for the one pixel at once and then walks the chain through
+//     the table: two rounds settle the 15 samples that can be open.
+// Every record that is written was computed from the exact counter of the reference's order, so
+// the result is bit-identical to sample-after-sample; only the chain of spp dependent
+// traversals is gone: no pixel needs more than four (Multi-GPU).
+struct PrimaryTrace {
+    uint32_t delta[2];               // draws the sample consumes
+    float rec[2][7];
+    int model[2];
+    int32_t id[2];
+    float t[2];
+};
+
+template <bool CULL>
+__device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv &env, uint32_t lane,
+                                              const uint32_t pix[2], const uint32_t ctr[2],
+                                              const bool live[2], PrimaryTrace &o, uint32_t &cost)
+{
+    const DevView &v = A.v;
+    const uint32_t L = (uint32_t)v.n_lights;
+    const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
+    RayPair w;
+    {
+        v3 ro[2], rd[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            // kernel.cu:65-73 with the H4 convention: the jitter is (.x, .y) of one
+            // curand_uniform4 of the pixel's own stream
+            float u[4];
+            pixel_uniform4(pix[h], ctr[h], u);
+            int x = (int)(pix[h] % (uint32_t)v.width), y = (int)(pix[h] / (uint32_t)v.width);
+            Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
+            ro[h] = r.o; rd[h] = r.d;
+        }
+        pair_set(w, ro, rd, inf2, none2, live, A.T.tv.extent);
+    }
+    traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            o.rec[h][k] = 0.0f;
+        o.delta[h] = 0u;
+        o.model[h] = -1;                                     // miss: PathTracer.cu:64 -> return res
+        o.t[h] = h ? w.best.y : w.best.x;
+        o.id[h] = h ? w.idy : w.idx;
+        if (!live[h])
+            continue;
+        const bool ishit = scene_ishit(o.t[h]) && o.id[h] >= 0;
+        // the jitter + tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
+        o.delta[h] = 2u + (ishit ? L : 0u);
+        if (ishit) {
+            Ray r;
+            r.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+            r.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+            Hit H;
+            fill_hit(v, r, o.id[h], H);
+            const float wo_y = local_y(H, neg(r.d));         // Object.cu:107-110 on wo = -r.dir
+            // PathTracer.cu:76-77: only whether the BRDF sample is usable matters at depth 0
+            float u[4];
+            pixel_uniform4(pix[h], ctr[h] + 1u, u);
+            v3 wi;
+            float pdf;
+            v3 f = rec_sample_f_y(H, v.models[H.model], wo_y, wi, pdf, u[0], u[1]);
+            if (!(pdf < 0.0001f || length(f) < 0.0001f))
+                o.delta[h] += 1u;                            // the next iteration's draw (:27) before its break (:64)
+            o.rec[h][0] = H.pos.x; o.rec[h][1] = H.pos.y; o.rec[h][2] = H.pos.z;
+            o.rec[h][3] = H.normal.x; o.rec[h][4] = H.normal.y; o.rec[h][5] = H.normal.z;
+            o.rec[h][6] = wo_y;
+            o.model[h] = H.model;
+        }
+    }
+}
+
+// The record of sample s of local pixel p, traced from counter ctr.
+__device__ __forceinline__ void write_primary(const BatchArgs &A, const PrimaryTrace &o, int h,
+                                              uint32_t s, uint32_t p, uint32_t ctr)
+{
+    const size_t i = (size_t)s * A.b.stride + p;
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        A.b.f[k][i] = o.rec[h][k];
+    A.b.f[7][i] = __int_as_float(o.model[h]);
+    if (s + 1u == A.n_samples) {                             // id / t buffers: the last sample's primary hit
+        A.v.first_id[p] = o.id[h];
+        A.v.first_t[p] = o.t[h];
+        A.v.rng_ctr[p] = ctr + o.delta[h];
+    }
+}
+
+template <bool CULL>
+__device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
+                                             uint32_t lane)
+{
+    const DevView &v = A.v;
+    const uint32_t L = (uint32_t)v.n_lights;
+    const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u, ss = 1u << A.ss_log2;
+    uint32_t cost = 0;
+    uint32_t q[2], smp[2], p[2], pix[2], base_c[2], base_s[2], dhat[2];
+    bool todo[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t r = (uint32_t)h * 64u + lane;
+        q[h] = r & px_mask;
+        smp[h] = r >> px_log2;
+        const uint32_t pl = (unit << px_log2) + q[h];
+        todo[h] = pl < A.n && smp[h] < A.n_samples;
+        p[h] = min(pl, A.n - 1u);
+        pix[h] = v.pixmap[p[h]];
+        base_c[h] = v.rng_ctr[p[h]];
+        base_s[h] = 0u;
+        // expected draws per sample: what the pixel's last sample before this batch did
+        // (first_id), a hit when there is none yet
+        dhat[h] = (A.predict_hit || v.first_id[p[h]] >= 0) ? 3u + L : 2u;
+    }
+    for (int round = 0; round < 2; round++) {
+        if (!__ballot(todo[0] | todo[1]))
+            return;
+        uint32_t ctr[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            ctr[h] = base_c[h] + (smp[h] - base_s[h]) * dhat[h];
+        PrimaryTrace o;
+        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost);
+        // first sample of each pixel whose draw count is not the expected one
+        const unsigned long long m0 = __ballot(todo[0] && o.delta[0] != dhat[0]);
+        const unsigned long long m1 = __ballot(todo[1] && o.delta[1] != dhat[1]);
+        uint32_t first[2], src[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            first[h] = ss;
+            for (uint32_t k = ss; k-- > 0u;) {
+                const uint32_t r = (k << px_log2) + q[h];
+                const bool bit = (((r < 64u ? m0 : m1) >> (r & 63u)) & 1ull) != 0ull;
+                first[h] = bit ? k : first[h];
+            }
+            src[h] = (min(first[h], ss - 1u) << px_log2) + q[h];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            // its draw count, from the lane that holds it
+            const uint32_t lo = (uint32_t)__shfl((int)o.delta[0], (int)(src[h] & 63u));
+            const uint32_t hi = (uint32_t)__shfl((int)o.delta[1], (int)(src[h] & 63u));
+            const uint32_t dj = src[h] < 64u ? lo : hi;
+            if (todo[h] && smp[h] <= first[h]) {             // traced from the right counter: final
+                write_primary(A, o, h, smp[h], p[h], ctr[h]);
+                todo[h] = false;
+            }
+            if (first[h] < ss) {                             // the pixel goes on from behind sample `first`
+                base_c[h] += (first[h] - base_s[h]) * dhat[h] + dj;
+                base_s[h] = first[h] + 1u;
+                dhat[h] = dj;
+            }
+        }
+    }
+    // still open: the lane of a pixel's first open sample queues the pixel
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        if (todo[h] && smp[h] == base_s[h]) {
+            const uint32_t slot = atomicAdd(&A.hard_cnt[0], 1u);
+            A.hard_q[slot] = make_uint4(p[h], base_s[h], base_c[h], 0u);
+        }
+}
+
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 4) void k_primary_batch(const BatchArgs A, uint32_t *__restrict__ work,
+                                                             uint32_t *__restrict__ work_next, int dynamic)
+{
+    __shared__ uint32_t s_chunk;
+    const uint32_t lane = threadIdx.x & 63u;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    const ChunkFeedback none{};
+    const uint32_t px = kPathChunk >> A.ss_log2;
+    run_chunks<CULL>(
+        1u, (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane); },
+        [&](uint32_t, uint32_t) {});
+}
+
+// Candidate r of the table: level k = samples before it, of which b hits without and c hits with
+// a usable BRDF sample.  Levels start at k (k + 1) (k + 2) / 6; inside a level, t = b + c,
+// index t (t + 1) / 2 + c.
+constexpr uint32_t kHardLevels = 8;                          // 120 candidates <= 128 rays of a wave
+__device__ __forceinline__ uint32_t hard_level_off(uint32_t k) { return k * (k + 1u) * (k + 2u) / 6u; }
+
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
+{
+    const DevView &v = A.v;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t L = (uint32_t)v.n_lights;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    const uint32_t count = min(A.hard_cnt[0], A.n);
+    uint32_t cost = 0;
+    // this lane's two candidates
+    uint32_t ck[2], ca[2], cb[2], cc[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t r = (uint32_t)h * 64u + lane;
+        uint32_t k = 0;
+        while (k + 1u < kHardLevels && hard_level_off(k + 1u) <= r) k++;
+        const uint32_t rem = r - hard_level_off(k);
+        uint32_t t = 0;
+        while ((t + 1u) * (t + 2u) / 2u <= rem) t++;
+        ck[h] = r < hard_level_off(kHardLevels) ? k : kHardLevels;     // past the table: never live
+        cc[h] = rem - t * (t + 1u) / 2u;
+        cb[h] = t - cc[h];
+        ca[h] = k - min(t, k);
+    }
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0)
+            item = atomicAdd(&A.hard_cnt[1], 1u);
+        item = (uint32_t)__shfl((int)item, 0);
+        if (item >= count)
+            return;
+        const uint4 e = A.hard_q[item];
+        const uint32_t p = e.x;
+        uint32_t e_s = e.y, e_c = e.z;
+        const uint32_t pix1 = v.pixmap[p];
+        const uint32_t pix[2] = {pix1, pix1};
+        for (int round = 0; round < 16 && e_s < A.n_samples; round++) {
+            const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);
+            uint32_t ctr[2];
+            bool live[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                live[h] = ck[h] < e_n;
+                ctr[h] = e_c + 2u * ca[h] + (2u + L) * cb[h] + (3u + L) * cc[h];
+            }
+            PrimaryTrace o;
+            trace_primary<CULL>(A, env, lane, pix, ctr, live, o, cost);
+            const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
+            const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
+            const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
+            const unsigned long long b1 = __ballot(live[1] && o.delta[1] == 2u + L);
+            // walk the chain through the table (wave-uniform)
+            unsigned long long c0 = 0ull, c1 = 0ull;
+            uint32_t b = 0, c = 0, c_new = e_c;
+            for (uint32_t k = 0; k < e_n; k++) {
+                const uint32_t t = b + c;
+                const uint32_t r = hard_level_off(k) + t * (t + 1u) / 2u + c;
+                const unsigned long long bit = 1ull << (r & 63u);
+                if (r < 64u) c0 |= bit; else c1 |= bit;
+                if (((r < 64u ? u0 : u1) & bit) != 0ull)      { c_new += 3u + L; c++; }
+                else if (((r < 64u ? b0 : b1) & bit) != 0ull) { c_new += 2u + L; b++; }
+                else                                          { c_new += 2u; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if ((((h ? c1 : c0) >> lane) & 1ull) != 0ull)
+                    write_primary(A, o, h, e_s + ck[h], p, ctr[h]);
+            e_s += e_n;
+            e_c = c_new;
+        }
+    }
 }
 
 // One unit = 128 pixel-samples = px consecutive pixels (a compact patch of the image) x ss
@@ -1353,6 +1630,7 @@ static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, co
     A.T = trav_args(v);
     A.n = n; A.n_samples = n_samples;
     A.b = b;
+    A.hard_q = b.hard_q; A.hard_cnt = b.hard_cnt;
     A.occlusion = v.n_spheres == 0;
     A.ctl = ctl;
     return A;
@@ -1360,12 +1638,33 @@ static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, co
 
 void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next, const ChunkFeedback *fb)
+                    uint32_t *work_next, const ChunkFeedback *fb, bool first_batch)
 {
     if (n == 0 || n_samples == 0)
         return;
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
     const int dynamic = v.cull && v.tree.top >= 3;
+    static const bool sequential = [] { const char *e = std::getenv("RT_PRIMARY"); return e && e[0] == 's'; }();
+    if (n_samples <= 16u && !sequential) {
+        // all samples of the batch in one wave: the smallest power of two that holds them
+        A.predict_hit = first_batch ? 1u : 0u;
+        while ((1u << A.ss_log2) < n_samples) A.ss_log2++;
+        const uint32_t px = kPathChunk >> A.ss_log2;
+        const uint32_t units = (n + px - 1) / px;
+        const uint32_t g = std::min<uint32_t>(std::max<uint32_t>((units + 3) / 4, 1u),
+                                              (uint32_t)std::max(max_blocks, 1) * 4u);
+        (void)hipMemsetAsync(A.hard_cnt, 0, 2 * sizeof(uint32_t), s);
+        if (v.cull) k_primary_batch<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else        k_primary_batch<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        // the pixels it queued, one per wave (about 1 % of them at silhouettes; none: the waves leave at once)
+        const uint32_t gh = std::min<uint32_t>(std::max<uint32_t>((n + 31u) / 32u, 1u),
+                                               (uint32_t)std::max(max_blocks, 1) * 4u);
+        if (n_samples > 1u) {
+            if (v.cull) k_primary_hard<true><<<gh, kBlock, 0, s>>>(A);
+            else        k_primary_hard<false><<<gh, kBlock, 0, s>>>(A);
+        }
+        return;
+    }
     if (fb) A.fb = *fb;
     // The chain of a step runs through this kernel (sample after sample per chunk).  Sharing
     // a chunk among four waves shortens the chain but costs throughput: from 4x the mean

@@ -39,7 +39,6 @@ struct Lane {
     uint32_t *early[3] = {nullptr, nullptr, nullptr};
     uint8_t *flag[3] = {nullptr, nullptr, nullptr};
     FbCounts *cnt = nullptr;             // [3]
-    uint32_t *acc = nullptr;             // [chunks]
     uint32_t fb_slots = 0;
     uint32_t fb_seq = 0;                 // path launches so far (set rotation)
 };
@@ -186,8 +185,6 @@ int alloc_feedback(rt_context *c, Lane &L)
         if ((rc = dalloc(c, c->part_allocs, L.flag[s], chunks))) return rc;
         RT_HIP(c, hipMemset(L.flag[s], 0, std::max<size_t>(chunks, 1)));
     }
-    if ((rc = dalloc(c, c->part_allocs, L.acc, chunks))) return rc;
-    RT_HIP(c, hipMemset(L.acc, 0, std::max<size_t>(chunks, 1) * sizeof(uint32_t)));
     if ((rc = dalloc(c, c->part_allocs, L.cnt, 3))) return rc;
     RT_HIP(c, hipMemset(L.cnt, 0, 3 * sizeof(FbCounts)));
     L.fb_slots = (uint32_t)std::max<size_t>(chunks, 1);
@@ -234,7 +231,6 @@ int setup_partition(rt_context *c)
     W.lo = 0; W.hi = (uint32_t)n; W.seq = 0;
     if ((rc = dalloc(c, c->part_allocs, W.ctl, 1))) return rc;
     RT_HIP(c, hipMemset(W.ctl, 0, sizeof(Ctl)));
-    if ((rc = alloc_feedback(c, W))) return rc;
     if ((rc = dalloc(c, c->part_allocs, c->shade_ctl, 1))) return rc;
     RT_HIP(c, hipMemset(c->shade_ctl, 0, sizeof(Ctl)));
     c->shade_seq = 0;
@@ -247,7 +243,10 @@ int setup_partition(rt_context *c)
 int ensure_batches(rt_context *c, uint32_t cap)
 {
     if (cap <= c->batch_cap) return RT_OK;
-    const size_t n = (size_t)c->n_local * cap;
+    // unit-major records (rt_kernels.hip rec_index): whole units of 128 pixel-samples
+    uint32_t ss = 1;
+    while (ss < cap) ss *= 2;
+    const size_t n = (size_t)c->n_local * ss + 128;
     if (!c->batch[0].hard_q) {           // one queue: k_primary launches follow each other on one stream
         int rc = dalloc(c, c->part_allocs, c->batch[0].hard_q, (size_t)c->n_local);
         if (rc == RT_OK) rc = dalloc(c, c->part_allocs, c->batch[0].hard_cnt, 2);
@@ -260,7 +259,6 @@ int ensure_batches(rt_context *c, uint32_t cap)
             int rc = dalloc(c, c->part_allocs, c->batch[b].f[k], n);   // outgrown ones stay until re-partition
             if (rc) return rc;
         }
-        c->batch[b].stride = c->n_local;
     }
     c->batch_cap = cap;
     return RT_OK;
@@ -333,7 +331,6 @@ ChunkFeedback next_feedback(Lane &L)
     f.cnt_r = L.cnt + r; f.heavy_r = L.heavy[r]; f.early_r = L.early[r]; f.flag_r = L.flag[r];
     f.cnt_w = L.cnt + w; f.heavy_w = L.heavy[w]; f.early_w = L.early[w]; f.flag_w = L.flag[w];
     f.cnt_z = L.cnt + z;
-    f.acc = L.acc;
     f.n_slots = L.fb_slots;
     L.fb_seq++;
     return f;
@@ -426,7 +423,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
                  hipEventCreateWithFlags(&c->ev_shade_done[b], hipEventDisableTiming) == hipSuccess;
         if (!ok) rc = fail(c, RT_ERR_DEVICE, "rt_create: could not create pipeline streams");
     }
-    if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(16, std::atoi(e)));
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -594,10 +591,9 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
                 RT_HIP(c, hipStreamWaitEvent(sa, c->ev_shade_done[b], 0));
             hipEvent_t p0 = nullptr, p1 = nullptr, e0 = nullptr, e1 = nullptr;
             if (c->timing) { p0 = next_event2(c); p1 = next_event2(c); e0 = next_event(c); e1 = next_event(c); }
-            ChunkFeedback f = next_feedback(W);
             if (p0) (void)hipEventRecord(p0, sa);
             launch_primary(sa, c->v, c->n_local, S, c->batch[b], c->max_blocks, W.ctl,
-                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u], &f, c->cnt == 0);
+                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u], c->cnt == 0);
             W.seq++;
             if (p1) (void)hipEventRecord(p1, sa);
             RT_HIP(c, hipEventRecord(c->ev_prim_done[b], sa));

@@ -62,7 +62,6 @@ struct ChunkFeedback {
     uint32_t *early_w;
     uint8_t *flag_w;
     FbCounts *cnt_z;
-    uint32_t *acc;                       // per chunk: cost accumulator of sub-divided heavy chunks (k_primary)
     uint32_t n_slots;                    // entries of the heavy / early arrays (= chunks of the range)
 };
 
@@ -89,12 +88,12 @@ struct DevView {
 };
 
 // Records of one batch of samples of the depth-0 pipeline (k_primary -> k_shadow -> k_accum),
-// struct-of-arrays, sample-major: element s * stride + p of every array.
+// struct-of-arrays, unit-major: the 128 pixel-samples a wave works on are contiguous in every
+// array (rt_kernels.hip rec_index).
 //   f[0..2] hit position, overwritten by k_shadow with the sample's radiance
 //   f[3..5] normal   f[6] dot(-dir, normal)   f[7] model index as int bits, -1 = the ray missed
 struct SampleBatch {
     float *f[8];
-    uint32_t stride;                // pixels of the partition
     uint4 *hard_q;                  // k_primary's queue of pixels whose samples flip outcome: one entry per pixel
     uint32_t *hard_cnt;             // [0] queued, [1] taken
 };
@@ -110,7 +109,7 @@ constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (t
 // Depth-0 pipeline over the whole partition (n pixels), one batch of n_samples samples.
 void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next, const ChunkFeedback *fb, bool first_batch);
+                    uint32_t *work_next, bool first_batch);
 void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
                    uint32_t *work_next);

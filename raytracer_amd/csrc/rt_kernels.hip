@@ -730,9 +730,8 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
 // depends on how many chunks a launch has (launch_path).
 // The dispatch every chunked kernel here shares.  solo(chunk) runs one chunk on the calling
 // wave, coop(chunk) runs it on the whole block (cooperative form; needs feedback).
-// hm: cooperative units per heavy chunk (coop(chunk, sub), sub < hm).
 template <bool CULL, class Solo, class Coop>
-__device__ __forceinline__ void run_chunks(uint32_t hm, uint32_t n_chunks, const ChunkFeedback &fb,
+__device__ __forceinline__ void run_chunks(uint32_t n_chunks, const ChunkFeedback &fb,
                                            uint32_t heavy_x4, uint32_t *__restrict__ work,
                                            uint32_t *__restrict__ work_next, int dynamic,
                                            ChunkEnv &env, uint32_t *s_chunk, Solo solo, Coop coop)
@@ -767,9 +766,9 @@ __device__ __forceinline__ void run_chunks(uint32_t hm, uint32_t n_chunks, const
             __syncthreads();
             const uint32_t d = *s_chunk;
             __syncthreads();
-            if (d >= n_heavy * hm)
+            if (d >= n_heavy)
                 break;
-            coop(fb.heavy_r[d / hm], d % hm);
+            coop(fb.heavy_r[d]);
         }
     }
     // phase 2, one chunk per wave at a time: first the previous launch's early chunks,
@@ -826,9 +825,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     run_chunks<CULL>(
-        1u, n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
+        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t chunk) { path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
-        [&](uint32_t chunk, uint32_t) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+        [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
 }
 
 // ------------------------------------------------------------------ depth 0 in three kernels
@@ -850,164 +849,28 @@ struct BatchArgs {
     uint32_t n;                      // pixels of the partition
     uint32_t n_samples;              // samples in this batch
     SampleBatch b;
-    uint32_t ss_log2;                // k_shadow: log2 of the samples packed into one wave
-    uint32_t heavy_split;            // k_primary: cooperative units per heavy chunk (1 or 4 quarters)
-    uint32_t predict_hit;            // k_primary_batch: no sample yet to predict a pixel's draws from
-    uint4 *hard_q;                   // k_primary_batch -> k_primary_hard: (pixel, first open sample, its counter, -)
+    uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2): fixes the record layout
+    uint32_t predict_hit;            // k_primary: no sample yet to predict a pixel's draws from
+    uint4 *hard_q;                   // k_primary -> k_primary_hard: (pixel, first open sample, its counter, -)
     uint32_t *hard_cnt;              // [0] entries queued, [1] entries taken
     bool occlusion;
     Ctl *ctl;
-    ChunkFeedback fb;
-    uint32_t heavy_x4;
 };
 
-// COOP = false: the calling wave runs the whole chunk alone.  COOP = true (heavy chunks): the
-// block's four waves share the traversals by subtree, either of the whole chunk (sub =
-// kWholeChunk) or of QUARTER `sub` of it -- 32 pixels, an 8x4 patch, in lanes 0..31; the
-// chunk's four quarters then go to four blocks, sixteen waves in all on what sits on the
-// chain of the step (samples x costliest chunk), their costs meet in fb.acc[chunk], and the
-// last one to arrive classifies the chunk for the next launch.  Quarters pay off when the
-// launch has fewer chunks than resident waves (small partitions); they cost throughput.
-constexpr uint32_t kWholeChunk = 0xffffffffu;
-template <bool CULL, bool COOP>
-__device__ __forceinline__ void primary_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t chunk,
-                                              uint32_t sub, uint32_t lane, uint32_t wib,
-                                              unsigned long long *s_best, uint32_t *s_cost)
+// Element of the record arrays that holds sample s of local pixel p: unit-major -- the 128
+// pixel-samples (px pixels x ss samples) a wave of k_primary / k_shadow works on are
+// 512 contiguous bytes of every array.
+__device__ __forceinline__ size_t rec_index(uint32_t ss_log2, uint32_t p, uint32_t s)
 {
-    const DevView &v = A.v;
-    const bool writer = !COOP || wib == 0;
-    const int L = v.n_lights;
-    const float E = A.T.tv.extent;
-    uint32_t cost = 0;
-    if (COOP && threadIdx.x == 0)
-        *s_cost = 0;
-    uint32_t p[2], pix[2], draw[2];
-    bool mine[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const bool quarter = COOP && sub != kWholeChunk;
-        const uint32_t pl = quarter ? chunk * kPathChunk + sub * 32u + (lane & 31u)
-                                    : chunk * kPathChunk + (uint32_t)h * 64u + lane;
-        mine[h] = pl < A.n && (!quarter || (h == 0 && lane < 32u));
-        p[h] = min(pl, A.n - 1u);
-        pix[h] = v.pixmap[p[h]];
-        draw[h] = v.rng_ctr[p[h]];
-    }
-    const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
-    for (uint32_t s = 0; s < A.n_samples; s++) {
-        RayPair w;
-        {
-            v3 ro[2], rd[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                // kernel.cu:65-73 with the H4 convention: the jitter is (.x, .y) of one
-                // curand_uniform4 of the pixel's own stream
-                float u[4];
-                pixel_uniform4(pix[h], draw[h], u);
-                draw[h] += 1u;
-                int x = (int)(pix[h] % (uint32_t)v.width), y = (int)(pix[h] / (uint32_t)v.width);
-                Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
-                ro[h] = r.o; rd[h] = r.d;
-            }
-            pair_set(w, ro, rd, inf2, none2, mine, E);
-        }
-        traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            if (!mine[h])
-                continue;
-            const float t = h ? w.best.y : w.best.x;
-            const int32_t id = h ? w.idy : w.idx;
-            const bool ishit = scene_ishit(t) && id >= 0;
-            // draws of the bounce: tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
-            const uint32_t bd = draw[h];
-            draw[h] += 1u + (ishit ? (uint32_t)L : 0u);
-            float rec[7] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            int model = -1;                                  // miss: PathTracer.cu:64 -> return res
-            if (ishit) {
-                Ray r;
-                r.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
-                r.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
-                Hit H;
-                fill_hit(v, r, id, H);
-                const float wo_y = local_y(H, neg(r.d));     // Object.cu:107-110 on wo = -r.dir
-                // PathTracer.cu:76-77: only whether the BRDF sample is usable matters at depth 0
-                float u[4];
-                pixel_uniform4(pix[h], bd, u);
-                v3 wi;
-                float pdf;
-                v3 f = rec_sample_f_y(H, v.models[H.model], wo_y, wi, pdf, u[0], u[1]);
-                if (!(pdf < 0.0001f || length(f) < 0.0001f))
-                    draw[h] += 1u;                           // the next iteration's draw (:27) before its break (:64)
-                rec[0] = H.pos.x; rec[1] = H.pos.y; rec[2] = H.pos.z;
-                rec[3] = H.normal.x; rec[4] = H.normal.y; rec[5] = H.normal.z;
-                rec[6] = wo_y;
-                model = H.model;
-            }
-            if (writer) {
-                const size_t i = (size_t)s * A.b.stride + p[h];
-#pragma unroll
-                for (int k = 0; k < 7; k++)
-                    A.b.f[k][i] = rec[k];
-                A.b.f[7][i] = __int_as_float(model);
-                if (s + 1u == A.n_samples) {                 // id / t buffers: the last sample's primary hit
-                    v.first_id[p[h]] = id;
-                    v.first_t[p[h]] = t;
-                }
-            }
-        }
-    }
-    if (writer) {
-#pragma unroll
-        for (int h = 0; h < 2; h++)
-            if (mine[h])
-                v.rng_ctr[p[h]] = draw[h];
-    }
-    if (COOP) {
-        if (lane == 0) atomicAdd(s_cost, cost);
-        __syncthreads();
-        cost = *s_cost;
-        if (wib != 0)
-            return;
-    }
-    if (lane == 0 && env.feedback) {
-        if (COOP && sub != kWholeChunk) {
-            // count of quarters done in the top four bits, their summed cost below
-            const uint32_t old = atomicAdd(&A.fb.acc[chunk], (cost & 0x0fffffffu) + (1u << 28));
-            if ((old >> 28) == 3u) {
-                A.fb.acc[chunk] = 0u;
-                record_cost(A.fb, env, chunk, (old & 0x0fffffffu) + cost);
-            }
-        } else {
-            record_cost(A.fb, env, chunk, cost);
-        }
-    }
-}
-
-template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32_t *__restrict__ work,
-                                                       uint32_t *__restrict__ work_next, int dynamic)
-{
-    __shared__ unsigned long long s_best[128];
-    __shared__ uint32_t s_cost, s_chunk;
-    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-    const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
-    ChunkEnv env;
-    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
-    const uint32_t hm = A.heavy_split;
-    run_chunks<CULL>(
-        hm, n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t chunk) { primary_chunk<CULL, false>(A, env, chunk, 0u, lane, wib, nullptr, nullptr); },
-        [&](uint32_t chunk, uint32_t q) {
-            primary_chunk<CULL, true>(A, env, chunk, hm > 1u ? q : kWholeChunk, lane, wib, s_best, &s_cost);
-        });
+    const uint32_t px_log2 = 7u - ss_log2;
+    return ((size_t)(p >> px_log2) << 7) + (s << px_log2) + (p & ((1u << px_log2) - 1u));
 }
 
 // k_primary, all samples of a batch at once.  The samples of a pixel are chained only through
 // the NUMBER of draws each one consumes: 2 on a miss, 2 + lights on a hit, +1 if the hit's BRDF
 // sample is usable (PathTracer.cu:77) -- and that number is almost always the one of the sample
 // before.  Two kernels:
-//   k_primary_batch  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples; 8 x 16
+//   k_primary  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples; 8 x 16
 //     for a full batch).  Every sample's counter is PREDICTED from its pixel's expected draws
 //     per sample (round 0: what the pixel's last sample did; round 1: what the first
 //     mispredicted one did), all are traced together, and the prediction is checked pixel by
@@ -1095,7 +958,7 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
 __device__ __forceinline__ void write_primary(const BatchArgs &A, const PrimaryTrace &o, int h,
                                               uint32_t s, uint32_t p, uint32_t ctr)
 {
-    const size_t i = (size_t)s * A.b.stride + p;
+    const size_t i = rec_index(A.ss_log2, p, s);
 #pragma unroll
     for (int k = 0; k < 7; k++)
         A.b.f[k][i] = o.rec[h][k];
@@ -1129,7 +992,7 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
         base_c[h] = v.rng_ctr[p[h]];
         base_s[h] = 0u;
         // expected draws per sample: what the pixel's last sample before this batch did
-        // (first_id), a hit when there is none yet
+        // (first_id), a hit when there is none yet (a wrong guess costs a pixel one more round)
         dhat[h] = (A.predict_hit || v.first_id[p[h]] >= 0) ? 3u + L : 2u;
     }
     for (int round = 0; round < 2; round++) {
@@ -1182,7 +1045,7 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
 }
 
 template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_primary_batch(const BatchArgs A, uint32_t *__restrict__ work,
+__global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32_t *__restrict__ work,
                                                              uint32_t *__restrict__ work_next, int dynamic)
 {
     __shared__ uint32_t s_chunk;
@@ -1192,9 +1055,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_batch(const BatchArgs A, 
     const ChunkFeedback none{};
     const uint32_t px = kPathChunk >> A.ss_log2;
     run_chunks<CULL>(
-        1u, (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
+        (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane); },
-        [&](uint32_t, uint32_t) {});
+        [&](uint32_t) {});
 }
 
 // Candidate r of the table: level k = samples before it, of which b hits without and c hits with
@@ -1284,13 +1147,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
 // (16 samples x 8 pixels against 1 x 128: C3 -27 % shadow time, C4 -40 %, C5 -68 %).
 template <bool CULL>
 __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                             uint32_t n_groups, uint32_t lane, float *st)
+                                             uint32_t lane, float *st)
 {
     using State = RayState<true>;
     const DevView &v = A.v;
     const int L = v.n_lights;
     const float E = A.T.tv.extent;
-    const uint32_t sg = unit / n_groups, pg = unit - sg * n_groups;    // sample group, pixel group
     const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u;
     uint32_t cost = 0, n_shadow = 0;
     State S[2];
@@ -1299,8 +1161,8 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t r = (uint32_t)h * 64u + lane;
-        const uint32_t pl = (pg << px_log2) + (r & px_mask), s = (sg << A.ss_log2) + (r >> px_log2);
-        idx[h] = (size_t)min(s, A.n_samples - 1u) * A.b.stride + min(pl, A.n - 1u);
+        const uint32_t pl = (unit << px_log2) + (r & px_mask), s = r >> px_log2;
+        idx[h] = ((size_t)unit << 7) + r;                    // rec_index(pl, s)
         S[h] = State{};
         S[h].model = (pl < A.n && s < A.n_samples) ? __float_as_int(A.b.f[7][idx[h]]) : -1;
         hit[h] = S[h].model >= 0;
@@ -1392,26 +1254,24 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     const ChunkFeedback none{};
-    const uint32_t px = kPathChunk >> A.ss_log2, ss = 1u << A.ss_log2;
-    const uint32_t n_groups = (A.n + px - 1u) / px;
-    const uint32_t s_groups = (A.n_samples + ss - 1u) / ss;
+    const uint32_t px = kPathChunk >> A.ss_log2;
     run_chunks<CULL>(
-        1u, n_groups * s_groups, none, 0u, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, n_groups, lane, st); },
-        [&](uint32_t, uint32_t) {});
+        (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, lane, st); },
+        [&](uint32_t) {});
 }
 
 // kernel.cu:65-66,75,77 for the S samples of a batch, in sample order; cnt0 = samples
 // accumulated before the batch.  A miss contributes res = 0 (PathTracer.cu:64).
 __global__ void k_accum(SampleBatch b, float4 *__restrict__ fb, uint32_t n, uint32_t n_samples,
-                        int cnt0)
+                        uint32_t ss_log2, int cnt0)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n)
         return;
     float4 prev = fb[p];
     for (uint32_t s = 0; s < n_samples; s++) {
-        const size_t i = (size_t)s * b.stride + p;
+        const size_t i = rec_index(ss_log2, p, s);
         const bool hit = __float_as_int(b.f[7][i]) >= 0;
         const float rx = hit ? b.f[0][i] : 0.0f, ry = hit ? b.f[1][i] : 0.0f, rz = hit ? b.f[2][i] : 0.0f;
         const int cnt = cnt0 + (int)s + 1;
@@ -1623,12 +1483,21 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     }
 }
 
+// Samples a wave holds: the smallest power of two that takes the whole batch (<= 16).
+static uint32_t batch_ss_log2(uint32_t n_samples)
+{
+    uint32_t l = 0;
+    while (l < 4u && (1u << l) < n_samples) l++;
+    return l;
+}
+
 static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, const SampleBatch &b, Ctl *ctl)
 {
     BatchArgs A{};
     A.v = v;
     A.T = trav_args(v);
     A.n = n; A.n_samples = n_samples;
+    A.ss_log2 = batch_ss_log2(n_samples);
     A.b = b;
     A.hard_q = b.hard_q; A.hard_cnt = b.hard_cnt;
     A.occlusion = v.n_spheres == 0;
@@ -1638,45 +1507,26 @@ static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, co
 
 void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next, const ChunkFeedback *fb, bool first_batch)
+                    uint32_t *work_next, bool first_batch)
 {
     if (n == 0 || n_samples == 0)
         return;
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
     const int dynamic = v.cull && v.tree.top >= 3;
-    static const bool sequential = [] { const char *e = std::getenv("RT_PRIMARY"); return e && e[0] == 's'; }();
-    if (n_samples <= 16u && !sequential) {
-        // all samples of the batch in one wave: the smallest power of two that holds them
-        A.predict_hit = first_batch ? 1u : 0u;
-        while ((1u << A.ss_log2) < n_samples) A.ss_log2++;
-        const uint32_t px = kPathChunk >> A.ss_log2;
-        const uint32_t units = (n + px - 1) / px;
-        const uint32_t g = std::min<uint32_t>(std::max<uint32_t>((units + 3) / 4, 1u),
-                                              (uint32_t)std::max(max_blocks, 1) * 4u);
-        (void)hipMemsetAsync(A.hard_cnt, 0, 2 * sizeof(uint32_t), s);
-        if (v.cull) k_primary_batch<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else        k_primary_batch<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        // the pixels it queued, one per wave (about 1 % of them at silhouettes; none: the waves leave at once)
-        const uint32_t gh = std::min<uint32_t>(std::max<uint32_t>((n + 31u) / 32u, 1u),
-                                               (uint32_t)std::max(max_blocks, 1) * 4u);
-        if (n_samples > 1u) {
-            if (v.cull) k_primary_hard<true><<<gh, kBlock, 0, s>>>(A);
-            else        k_primary_hard<false><<<gh, kBlock, 0, s>>>(A);
-        }
-        return;
-    }
-    if (fb) A.fb = *fb;
-    // The chain of a step runs through this kernel (sample after sample per chunk).  Sharing
-    // a chunk among four waves shortens the chain but costs throughput: from 4x the mean
-    // cost when the launch has few chunks per resident wave, from 8x otherwise (measured on
-    // whole frames and 1/8 partitions of C3 and C4).
-    const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
-    const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * 4u * (kBlock / 64);
-    A.heavy_x4 = n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
-    A.heavy_split = n_chunks <= slots ? 4u : 1u;
-    const uint32_t g = grid_for_chunks(n, max_blocks * 4);
+    A.predict_hit = first_batch ? 1u : 0u;
+    const uint32_t px = kPathChunk >> A.ss_log2;
+    const uint32_t units = (n + px - 1) / px;
+    const uint32_t cap = (uint32_t)std::max(max_blocks, 1) * 4u;
+    (void)hipMemsetAsync(A.hard_cnt, 0, 2 * sizeof(uint32_t), s);
+    const uint32_t g = std::min<uint32_t>(std::max<uint32_t>((units + 3) / 4, 1u), cap);
     if (v.cull) k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     else        k_primary<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    // the pixels it queued, one per wave (about 1 % of them, at silhouettes; the other waves leave at once)
+    if (n_samples > 1u) {
+        const uint32_t gh = std::min<uint32_t>(std::max<uint32_t>((n + 31u) / 32u, 1u), cap);
+        if (v.cull) k_primary_hard<true><<<gh, kBlock, 0, s>>>(A);
+        else        k_primary_hard<false><<<gh, kBlock, 0, s>>>(A);
+    }
 }
 
 void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
@@ -1687,11 +1537,8 @@ void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_sampl
         return;
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
     const int dynamic = v.cull && v.tree.top >= 3;
-    // samples per wave: the largest power of two the batch fills, at most 16
-    A.ss_log2 = 0;
-    while (A.ss_log2 < 4u && (2u << A.ss_log2) <= n_samples) A.ss_log2++;
-    const uint32_t px = kPathChunk >> A.ss_log2, ss = 1u << A.ss_log2;
-    const unsigned long long units = (unsigned long long)((n + px - 1) / px) * ((n_samples + ss - 1) / ss);
+    const uint32_t px = kPathChunk >> A.ss_log2;
+    const unsigned long long units = (n + px - 1) / px;
     const uint32_t g = (uint32_t)std::min<unsigned long long>(
         std::max<unsigned long long>((units + 3) / 4, 1ull), (unsigned long long)std::max(max_blocks, 1) * 4);
     if (v.cull) k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
@@ -1702,7 +1549,7 @@ void launch_accum(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_sample
                   const SampleBatch &b, int cnt0)
 {
     if (n && n_samples)
-        k_accum<<<(n + 255) / 256, 256, 0, s>>>(b, v.fb, n, n_samples, cnt0);
+        k_accum<<<(n + 255) / 256, 256, 0, s>>>(b, v.fb, n, n_samples, batch_ss_log2(n_samples), cnt0);
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

@@ -182,6 +182,59 @@ def test_heavy_chunk_feedback_and_cooperative_form(gpu_ctx_factory):
     check_images(out[0], ref, st)
 
 
+def flicker_scene(rng, n_tris):
+    """Small triangles scattered through the view with RANDOM vertex normals: most pixels flip
+    between hit and miss from sample to sample, and many hits have wo.n < 0 (an unusable
+    BRDF sample, PathTracer.cu:77) -- every draw count a sample can have, in every order."""
+    b = SceneBuilder()
+    c = rng.uniform([-220, -130, -520], [220, 170, -380], (n_tris, 1, 3))
+    P = (c + rng.normal(size=(n_tris, 3, 3)) * rng.choice([3.0, 8.0, 16.0], (n_tris, 1, 1))).astype(np.float32)
+    N = rng.normal(size=(n_tris, 3, 3)).astype(np.float32)
+    N /= np.linalg.norm(N, axis=2, keepdims=True)
+    h = n_tris // 2
+    b.add_mesh(P[:h], N[:h], identity(), (0.7, 0.7, 0.7))
+    b.add_mesh(P[h:], N[h:], identity(), (0.6, 0.7, 0.6))
+    b.add_point_light((-300.0, 300.0, -100.0), (3.0e5, 2.5e5, 2.0e5))
+    b.add_point_light((250.0, 150.0, -200.0), (1.0e5, 1.5e5, 2.0e5))
+    return b.build()
+
+
+@pytest.mark.parametrize("spp", [16, 21])
+def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
+    """rt_render(n, 0) over a deep tree traces all samples of a batch at once from PREDICTED
+    RNG counters and settles mispredicted pixels by enumeration (k_primary, k_primary_hard).
+    On a scene built to defeat the prediction it must equal (a) the oracle, (b) the same
+    samples rendered one call at a time, (c) the unculled per-sample path kernel -- in every
+    bit of image, id and t buffers, and in the ray counts."""
+    scene = flicker_scene(np.random.default_rng(31), 3000)
+    cam = CameraArgs.for_image(80, 48, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    ctx = gpu_ctx_factory(80, 48)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    out, stats = [], []
+    for mode in ("batched", "one by one", "scan"):
+        ctx.set_culling(0 if mode == "scan" else 1)
+        ctx.reset()
+        ctx.reset_stats()
+        if mode == "one by one":
+            for _ in range(spp):
+                ctx.render(1, 0)
+        else:
+            ctx.render(spp, 0)
+        out.append(ctx.read_framebuffer())
+        stats.append(ctx.stats())
+    ctx.set_culling(1)
+    for other in (1, 2):
+        for k in ("rgba", "t", "prim_id"):
+            assert np.array_equal(out[0][k].view(np.uint32), out[other][k].view(np.uint32)), (other, k)
+        assert stats[0].shadow_rays == stats[other].shadow_rays
+    hit = out[0]["prim_id"] >= 0
+    assert 0.15 < hit.mean() < 0.85                     # the last sample's hits: a coin flip per pixel
+    if spp == 16:
+        ref = orc.render(scene, cam, 80, 48, spp=spp, max_depth=0)
+        check_images(out[0], ref, stats[0])
+
+
 @pytest.mark.parametrize("depth,spp", [(0, 1), (0, 3), (12, 2)])
 def test_c1_sphere(gpu_ctx_factory, depth, spp):
     cfg = scenes.c1(160, 120)
@@ -198,7 +251,7 @@ def test_c2_cornell(gpu_ctx_factory, depth, spp):
     assert (got["prim_id"] >= 0).mean() > 0.95
 
 
-@pytest.mark.parametrize("depth,spp", [(0, 2), (12, 2)])
+@pytest.mark.parametrize("depth,spp", [(0, 2), (0, 16), (12, 2)])
 def test_c3_decimated(gpu_ctx_factory, depth, spp):
     cfg = scenes.c3(128, 72, lon=24, lat=24, ground=(8, 4))
     got, ref, st = render_both(gpu_ctx_factory, cfg.scene, cfg.camera, 128, 72, spp, depth)

@@ -205,6 +205,7 @@ int setup_partition(rt_context *c)
         RT_HIP(c, hipMemcpy(pixmap, c->h_pixmap.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     v.pixmap = pixmap;
     if ((rc = dalloc(c, c->part_allocs, v.rng_ctr, n))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, v.last_draws, n))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.fb, n))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.first_id, n))) return rc;
     if ((rc = dalloc(c, c->part_allocs, v.first_t, n))) return rc;
@@ -270,6 +271,7 @@ int do_reset(rt_context *c)
     DevView &v = c->v;
     if (n) {
         RT_HIP(c, hipMemsetAsync(v.rng_ctr, 0, n * sizeof(uint32_t), c->stream));
+        RT_HIP(c, hipMemsetAsync(v.last_draws, 0, n * sizeof(uint32_t), c->stream));
         RT_HIP(c, hipMemsetAsync(v.fb, 0, n * sizeof(float4), c->stream));
         RT_HIP(c, hipMemsetAsync(v.first_t, 0, n * sizeof(float), c->stream));
         launch_fill_i32(c->stream, v.first_id, n, -1);
@@ -593,7 +595,7 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             if (c->timing) { p0 = next_event2(c); p1 = next_event2(c); e0 = next_event(c); e1 = next_event(c); }
             if (p0) (void)hipEventRecord(p0, sa);
             launch_primary(sa, c->v, c->n_local, S, c->batch[b], c->max_blocks, W.ctl,
-                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u], c->cnt == 0);
+                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u]);
             W.seq++;
             if (p1) (void)hipEventRecord(p1, sa);
             RT_HIP(c, hipEventRecord(c->ev_prim_done[b], sa));

@@ -82,6 +82,7 @@ struct DevView {
     // persistent per local pixel
     const uint32_t *pixmap;         // local index -> global pixel index y*W + x
     uint32_t *rng_ctr;              // next Philox draw of the pixel's stream
+    uint32_t *last_draws;           // draws the pixel's latest depth-0 batch sample consumed (0: none yet); k_primary predicts from it
     float4 *fb;                     // RGBA32F running mean
     int32_t *first_id;
     float *first_t;
@@ -109,7 +110,7 @@ constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (t
 // Depth-0 pipeline over the whole partition (n pixels), one batch of n_samples samples.
 void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next, bool first_batch);
+                    uint32_t *work_next);
 void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
                    uint32_t *work_next);

@@ -850,7 +850,6 @@ struct BatchArgs {
     uint32_t n_samples;              // samples in this batch
     SampleBatch b;
     uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2): fixes the record layout
-    uint32_t predict_hit;            // k_primary: no sample yet to predict a pixel's draws from
     uint4 *hard_q;                   // k_primary -> k_primary_hard: (pixel, first open sample, its counter, -)
     uint32_t *hard_cnt;              // [0] entries queued, [1] entries taken
     bool occlusion;
@@ -967,6 +966,7 @@ __device__ __forceinline__ void write_primary(const BatchArgs &A, const PrimaryT
         A.v.first_id[p] = o.id[h];
         A.v.first_t[p] = o.t[h];
         A.v.rng_ctr[p] = ctr + o.delta[h];
+        A.v.last_draws[p] = o.delta[h];
     }
 }
 
@@ -991,9 +991,10 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
         pix[h] = v.pixmap[p[h]];
         base_c[h] = v.rng_ctr[p[h]];
         base_s[h] = 0u;
-        // expected draws per sample: what the pixel's last sample before this batch did
-        // (first_id), a hit when there is none yet (a wrong guess costs a pixel one more round)
-        dhat[h] = (A.predict_hit || v.first_id[p[h]] >= 0) ? 3u + L : 2u;
+        // expected draws per sample: what the pixel's last sample before this batch consumed,
+        // a hit's when there is none yet (a wrong guess costs the pixel one more round)
+        const uint32_t last = v.last_draws[p[h]];
+        dhat[h] = last ? last : 3u + L;
     }
     for (int round = 0; round < 2; round++) {
         if (!__ballot(todo[0] | todo[1]))
@@ -1507,13 +1508,12 @@ static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, co
 
 void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next, bool first_batch)
+                    uint32_t *work_next)
 {
     if (n == 0 || n_samples == 0)
         return;
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
     const int dynamic = v.cull && v.tree.top >= 3;
-    A.predict_hit = first_batch ? 1u : 0u;
     const uint32_t px = kPathChunk >> A.ss_log2;
     const uint32_t units = (n + px - 1) / px;
     const uint32_t cap = (uint32_t)std::max(max_blocks, 1) * 4u;

@@ -263,8 +263,11 @@ def main():
         if pipeline:
             out["primary_kernel"] = {"kernel": "k_primary", "launches_timed": int(st.primary_launches),
                                      "avg_launch_ms": st.primary_ms / max(1, st.primary_launches),
-                                     "note": "closest hit of the camera rays, sample after sample per "
-                                             "chunk; runs a batch ahead of k_shadow on its own stream"}
+                                     "note": "closest hits of the camera rays of a whole batch of samples, "
+                                             "traced from predicted RNG counters (k_primary, then "
+                                             "k_primary_hard for the pixels the prediction failed on; "
+                                             "timed together); runs a batch ahead of k_shadow on its "
+                                             "own stream"}
         valu = measured_counter(cfg.name, kernel, "SQ_INSTS_VALU")
         if valu and k_ms > 0:
             prop = torch.cuda.get_device_properties(dev)
@@ -273,7 +276,8 @@ def main():
             if pipeline:
                 # k_primary and k_shadow overlap on two streams: price both kernels'
                 # instructions of one batch against the wall time of one batch
-                valu_p = measured_counter(cfg.name, "k_primary", "SQ_INSTS_VALU") or 0.0
+                valu_p = ((measured_counter(cfg.name, "k_primary", "SQ_INSTS_VALU") or 0.0) +
+                          (measured_counter(cfg.name, "k_primary_hard", "SQ_INSTS_VALU") or 0.0))
                 batch_s = dt / max(1.0, float(launches))
                 frac = (valu + valu_p) * 4.0 / (batch_s * simds * clk_hz)
                 insts = valu + valu_p

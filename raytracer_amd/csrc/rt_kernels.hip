@@ -884,6 +884,10 @@ __device__ __forceinline__ size_t rec_index(uint32_t ss_log2, uint32_t p, uint32
 // Every record that is written was computed from the exact counter of the reference's order, so
 // the result is bit-identical to sample-after-sample; only the chain of spp dependent
 // traversals is gone: no pixel needs more than four (Multi-GPU).
+// What a lane carries across a traversal is parked in LDS (slot i of a lane: st[i * kBlock]),
+// as in the path kernel: the closest-hit traversal needs the register file to itself, and what
+// the compiler would otherwise spill goes to scratch memory and from there to HBM.
+constexpr int kPrimSlots = 12;       // 0-1 pixel, 2-3 counter, 4 live bits; 5-10 the caller's
 struct PrimaryTrace {
     uint32_t delta[2];               // draws the sample consumes
     float rec[2][7];
@@ -894,8 +898,8 @@ struct PrimaryTrace {
 
 template <bool CULL>
 __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv &env, uint32_t lane,
-                                              const uint32_t pix[2], const uint32_t ctr[2],
-                                              const bool live[2], PrimaryTrace &o, uint32_t &cost)
+                                              uint32_t pix[2], uint32_t ctr[2], bool live[2],
+                                              PrimaryTrace &o, uint32_t &cost, uint32_t *st)
 {
     const DevView &v = A.v;
     const uint32_t L = (uint32_t)v.n_lights;
@@ -915,7 +919,15 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
         }
         pair_set(w, ro, rd, inf2, none2, live, A.T.tv.extent);
     }
+    st[0 * kBlock] = pix[0]; st[1 * kBlock] = pix[1];
+    st[2 * kBlock] = ctr[0]; st[3 * kBlock] = ctr[1];
+    st[4 * kBlock] = (live[0] ? 1u : 0u) | (live[1] ? 2u : 0u);
+    asm volatile("" ::: "memory");
     traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
+    asm volatile("" ::: "memory");
+    pix[0] = st[0 * kBlock]; pix[1] = st[1 * kBlock];
+    ctr[0] = st[2 * kBlock]; ctr[1] = st[3 * kBlock];
+    live[0] = (st[4 * kBlock] & 1u) != 0u; live[1] = (st[4 * kBlock] & 2u) != 0u;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
 #pragma unroll
@@ -972,28 +984,26 @@ __device__ __forceinline__ void write_primary(const BatchArgs &A, const PrimaryT
 
 template <bool CULL>
 __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                             uint32_t lane)
+                                             uint32_t lane, uint32_t *st)
 {
     const DevView &v = A.v;
     const uint32_t L = (uint32_t)v.n_lights;
     const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u, ss = 1u << A.ss_log2;
     uint32_t cost = 0;
-    uint32_t q[2], smp[2], p[2], pix[2], base_c[2], base_s[2], dhat[2];
+    uint32_t pix[2], base_c[2], base_s[2], dhat[2];
     bool todo[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t r = (uint32_t)h * 64u + lane;
-        q[h] = r & px_mask;
-        smp[h] = r >> px_log2;
-        const uint32_t pl = (unit << px_log2) + q[h];
-        todo[h] = pl < A.n && smp[h] < A.n_samples;
-        p[h] = min(pl, A.n - 1u);
-        pix[h] = v.pixmap[p[h]];
-        base_c[h] = v.rng_ctr[p[h]];
+        const uint32_t pl = (unit << px_log2) + (r & px_mask);
+        todo[h] = pl < A.n && (r >> px_log2) < A.n_samples;
+        const uint32_t p = min(pl, A.n - 1u);
+        pix[h] = v.pixmap[p];
+        base_c[h] = v.rng_ctr[p];
         base_s[h] = 0u;
         // expected draws per sample: what the pixel's last sample before this batch consumed,
         // a hit's when there is none yet (a wrong guess costs the pixel one more round)
-        const uint32_t last = v.last_draws[p[h]];
+        const uint32_t last = v.last_draws[p];
         dhat[h] = last ? last : 3u + L;
     }
     for (int round = 0; round < 2; round++) {
@@ -1001,10 +1011,26 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
             return;
         uint32_t ctr[2];
 #pragma unroll
-        for (int h = 0; h < 2; h++)
-            ctr[h] = base_c[h] + (smp[h] - base_s[h]) * dhat[h];
+        for (int h = 0; h < 2; h++) {
+            const uint32_t smp = ((uint32_t)h * 64u + lane) >> px_log2;
+            ctr[h] = base_c[h] + (smp - base_s[h]) * dhat[h];
+            st[(5 + h) * kBlock] = base_c[h];
+            st[(7 + h) * kBlock] = base_s[h];
+            st[(9 + h) * kBlock] = dhat[h];
+        }
         PrimaryTrace o;
-        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost);
+        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, st);
+        uint32_t q[2], smp[2], p[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t r = (uint32_t)h * 64u + lane;
+            q[h] = r & px_mask;
+            smp[h] = r >> px_log2;
+            p[h] = min((unit << px_log2) + q[h], A.n - 1u);
+            base_c[h] = st[(5 + h) * kBlock];
+            base_s[h] = st[(7 + h) * kBlock];
+            dhat[h] = st[(9 + h) * kBlock];
+        }
         // first sample of each pixel whose draw count is not the expected one
         const unsigned long long m0 = __ballot(todo[0] && o.delta[0] != dhat[0]);
         const unsigned long long m1 = __ballot(todo[1] && o.delta[1] != dhat[1]);
@@ -1034,15 +1060,13 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
                 base_s[h] = first[h] + 1u;
                 dhat[h] = dj;
             }
+            // still open after the second round: the lane of a pixel's first open sample queues the pixel
+            if (round == 1 && todo[h] && smp[h] == base_s[h]) {
+                const uint32_t slot = atomicAdd(&A.hard_cnt[0], 1u);
+                A.hard_q[slot] = make_uint4(p[h], base_s[h], base_c[h], 0u);
+            }
         }
     }
-    // still open: the lane of a pixel's first open sample queues the pixel
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-        if (todo[h] && smp[h] == base_s[h]) {
-            const uint32_t slot = atomicAdd(&A.hard_cnt[0], 1u);
-            A.hard_q[slot] = make_uint4(p[h], base_s[h], base_c[h], 0u);
-        }
 }
 
 template <bool CULL>
@@ -1050,6 +1074,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32
                                                              uint32_t *__restrict__ work_next, int dynamic)
 {
     __shared__ uint32_t s_chunk;
+    __shared__ uint32_t s_stash[kPrimSlots][kBlock];
+    uint32_t *st = &s_stash[0][threadIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
@@ -1057,7 +1083,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32
     const uint32_t px = kPathChunk >> A.ss_log2;
     run_chunks<CULL>(
         (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane); },
+        [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane, st); },
         [&](uint32_t) {});
 }
 
@@ -1067,9 +1093,26 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32
 constexpr uint32_t kHardLevels = 8;                          // 120 candidates <= 128 rays of a wave
 __device__ __forceinline__ uint32_t hard_level_off(uint32_t k) { return k * (k + 1u) * (k + 2u) / 6u; }
 
+// Candidate r of the table: k samples before it, of which b hits without and c hits with a
+// usable BRDF sample (a = k - b - c misses).  k = kHardLevels: past the table.
+__device__ __forceinline__ void hard_candidate(uint32_t r, uint32_t &k, uint32_t &a, uint32_t &b, uint32_t &c)
+{
+    k = 0;
+    while (k + 1u < kHardLevels && hard_level_off(k + 1u) <= r) k++;
+    const uint32_t rem = r - hard_level_off(k);
+    uint32_t t = 0;
+    while ((t + 1u) * (t + 2u) / 2u <= rem) t++;
+    c = rem - t * (t + 1u) / 2u;
+    b = t - c;
+    a = k - min(t, k);
+    if (r >= hard_level_off(kHardLevels)) k = kHardLevels;
+}
+
 template <bool CULL>
 __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
 {
+    __shared__ uint32_t s_stash[kPrimSlots][kBlock];
+    uint32_t *st = &s_stash[0][threadIdx.x];
     const DevView &v = A.v;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t L = (uint32_t)v.n_lights;
@@ -1077,44 +1120,31 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     const uint32_t count = min(A.hard_cnt[0], A.n);
     uint32_t cost = 0;
-    // this lane's two candidates
-    uint32_t ck[2], ca[2], cb[2], cc[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t r = (uint32_t)h * 64u + lane;
-        uint32_t k = 0;
-        while (k + 1u < kHardLevels && hard_level_off(k + 1u) <= r) k++;
-        const uint32_t rem = r - hard_level_off(k);
-        uint32_t t = 0;
-        while ((t + 1u) * (t + 2u) / 2u <= rem) t++;
-        ck[h] = r < hard_level_off(kHardLevels) ? k : kHardLevels;     // past the table: never live
-        cc[h] = rem - t * (t + 1u) / 2u;
-        cb[h] = t - cc[h];
-        ca[h] = k - min(t, k);
-    }
     for (;;) {
         uint32_t item = 0;
         if (lane == 0)
             item = atomicAdd(&A.hard_cnt[1], 1u);
-        item = (uint32_t)__shfl((int)item, 0);
+        item = (uint32_t)__builtin_amdgcn_readfirstlane(item);
         if (item >= count)
             return;
         const uint4 e = A.hard_q[item];
-        const uint32_t p = e.x;
-        uint32_t e_s = e.y, e_c = e.z;
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane(e.x);
+        uint32_t e_s = (uint32_t)__builtin_amdgcn_readfirstlane(e.y);
+        uint32_t e_c = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
         const uint32_t pix1 = v.pixmap[p];
-        const uint32_t pix[2] = {pix1, pix1};
         for (int round = 0; round < 16 && e_s < A.n_samples; round++) {
             const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);
-            uint32_t ctr[2];
+            uint32_t pix[2] = {pix1, pix1}, ctr[2];
             bool live[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                live[h] = ck[h] < e_n;
-                ctr[h] = e_c + 2u * ca[h] + (2u + L) * cb[h] + (3u + L) * cc[h];
+                uint32_t k, a, b, c;
+                hard_candidate((uint32_t)h * 64u + lane, k, a, b, c);
+                live[h] = k < e_n;
+                ctr[h] = e_c + 2u * a + (2u + L) * b + (3u + L) * c;
             }
             PrimaryTrace o;
-            trace_primary<CULL>(A, env, lane, pix, ctr, live, o, cost);
+            trace_primary<CULL>(A, env, lane, pix, ctr, live, o, cost, st);
             const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
             const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
             const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
@@ -1133,8 +1163,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
             }
 #pragma unroll
             for (int h = 0; h < 2; h++)
-                if ((((h ? c1 : c0) >> lane) & 1ull) != 0ull)
-                    write_primary(A, o, h, e_s + ck[h], p, ctr[h]);
+                if ((((h ? c1 : c0) >> lane) & 1ull) != 0ull) {
+                    uint32_t k, ca, cb, cc;
+                    hard_candidate((uint32_t)h * 64u + lane, k, ca, cb, cc);
+                    write_primary(A, o, h, e_s + k, p, ctr[h]);
+                }
             e_s += e_n;
             e_c = c_new;
         }

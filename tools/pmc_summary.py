@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """Sum every counter of the given rocprofv3 counter_collection.csv files for the kernels whose
-name contains one of the given substrings; prints a "== kernel" section per substring with
-one line per counter: total and per launch.
+short name (namespace, template arguments and parameters stripped) is one of the given names;
+prints a "== kernel" section per name with one line per counter: total and per launch.
 
   python tools/pmc_summary.py <kernel[,kernel...]> file.csv [file.csv ...]"""
 import collections
 import csv
 import sys
+
+
+def short_name(k):
+    return k.split("(")[0].split("<")[0].split("::")[-1].replace("void ", "").strip()
 
 
 def main():
@@ -15,7 +19,7 @@ def main():
         disp = collections.defaultdict(set)
         for path in sys.argv[2:]:
             for r in csv.DictReader(open(path)):
-                if want not in r["Kernel_Name"]:
+                if want != short_name(r["Kernel_Name"]):
                     continue
                 tot[r["Counter_Name"]] += float(r["Counter_Value"])
                 disp[r["Counter_Name"]].add(r["Dispatch_Id"])

@@ -23,6 +23,6 @@ for c in c3 c2; do
   timeout -s KILL 120 rocprofv3 --pmc $SQ2 --output-format csv -d $O/sq2 -o $c -- python3 bench.py $A > $O/sq2_$c.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc $SQC --output-format csv -d $O/sqc -o $c -- python3 bench.py $A > $O/sqc_$c.log 2>&1
   python3 tools/pmc_traffic.py $c $O/fetch/${c}_counter_collection.csv $O/write/${c}_counter_collection.csv $O/traffic.json > $O/traffic_$c.txt
-  python3 tools/pmc_summary.py k_shadow,k_primary,k_path $O/sq1/${c}_counter_collection.csv $O/sq2/${c}_counter_collection.csv $O/sqc/${c}_counter_collection.csv > $O/sq_$c.txt
+  python3 tools/pmc_summary.py k_shadow,k_primary,k_primary_hard,k_path $O/sq1/${c}_counter_collection.csv $O/sq2/${c}_counter_collection.csv $O/sqc/${c}_counter_collection.csv > $O/sq_$c.txt
 done
 echo done

@@ -1525,13 +1525,13 @@ static uint32_t batch_ss_log2(uint32_t n_samples)
     return l;
 }
 
-// Blocks of a launch over `units` wave-sized units: at least 16 units per wave.  A small launch
+// Blocks of a launch over `units` wave-sized units: at least 24 units per wave.  A small launch
 // (a 1/8 partition) ends with its costliest units, and those finish sooner when fewer waves
-// share a SIMD with them (measured on a 1/8 partition of C3: 2 waves per SIMD 0.104 ms per
-// sample, 4 waves 0.116).
+// share a SIMD with them (measured on a 1/8 partition of C3, ms per sample: 4 waves per SIMD
+// 0.083, 2 to 3 waves 0.077; C4, whose launches are four times larger, wants all four).
 static uint32_t batch_grid(uint32_t units, uint32_t cap)
 {
-    return std::min<uint32_t>(std::max<uint32_t>(units / 64u, 1u), cap);
+    return std::min<uint32_t>(std::max<uint32_t>(units / 96u, 1u), cap);
 }
 
 static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, const SampleBatch &b, Ctl *ctl)

@@ -68,7 +68,7 @@ struct rt_context {
     DevView v{};                         // scene + per-pixel state
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
 
-    // depth-0 pipeline (k_primary -> k_shadow -> k_accum, rt_kernels.hip): `whole` spans the
+    // depth-0 pipeline (k_primary -> k_shadow, rt_kernels.hip): `whole` spans the
     // partition and carries k_primary's dispensers and feedback; k_shadow has its own control
     // block; two record buffers alternate by batch; stream / events as long as the context
     Lane whole;
@@ -603,11 +603,10 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             RT_HIP(c, hipEventRecord(c->ev_prim_done[b], sa));
             RT_HIP(c, hipStreamWaitEvent(sb, c->ev_prim_done[b], 0));
             if (e0) (void)hipEventRecord(e0, sb);
-            launch_shadow(sb, c->v, c->n_local, S, c->batch[b], c->max_blocks, c->shade_ctl,
+            launch_shadow(sb, c->v, c->n_local, S, c->batch[b], c->cnt, c->max_blocks, c->shade_ctl,
                           c->shade_ctl->work[c->shade_seq & 1u], c->shade_ctl->work[(c->shade_seq + 1u) & 1u]);
             c->shade_seq++;
             if (e1) (void)hipEventRecord(e1, sb);
-            launch_accum(sb, c->v, c->n_local, S, c->batch[b], c->cnt);
             RT_HIP(c, hipEventRecord(c->ev_shade_done[b], sb));
             c->launches++;
             c->cnt += (int)S;

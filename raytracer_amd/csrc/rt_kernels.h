@@ -88,10 +88,10 @@ struct DevView {
     float *first_t;
 };
 
-// Records of one batch of samples of the depth-0 pipeline (k_primary -> k_shadow -> k_accum),
+// Records of one batch of samples of the depth-0 pipeline (k_primary -> k_shadow),
 // struct-of-arrays, unit-major: the 128 pixel-samples a wave works on are contiguous in every
 // array (rt_kernels.hip rec_index).
-//   f[0..2] hit position, overwritten by k_shadow with the sample's radiance
+//   f[0..2] hit position
 //   f[3..5] normal   f[6] dot(-dir, normal)   f[7] model index as int bits, -1 = the ray missed
 struct SampleBatch {
     float *f[8];
@@ -112,10 +112,8 @@ void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samp
                     const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
                     uint32_t *work_next);
 void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                   const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
+                   const SampleBatch &b, int cnt0, int max_blocks, Ctl *ctl, uint32_t *work,
                    uint32_t *work_next);
-void launch_accum(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                  const SampleBatch &b, int cnt0);
 
 // Scene::hit on a queue of caller rays (rt_scene_hit).
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

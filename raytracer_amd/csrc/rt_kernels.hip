@@ -830,19 +830,21 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
         [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
 }
 
-// ------------------------------------------------------------------ depth 0 in three kernels
+// ------------------------------------------------------------------ depth 0: a pipeline over batches
 // With max_depth = 0 (primary hit + direct light, the benchmark mode) the samples of a pixel
 // depend on one another only through the closest hit of the camera ray: the pixel's Philox
 // counter advances by 1 (jitter) + 1 (PathTracer.cu:27) + one per light if the ray hit
 // (Scene.cu:87) + 1 if the BRDF sample is usable (PathTracer.cu:77, the discarded trace of the
-// next iteration).  The shadow rays -- most of the work -- do not feed back into it.  So:
-//   k_primary  for a batch of S samples, per chunk of 128 pixels and sample after sample: jitter,
-//              camera ray, closest hit, hit record; writes one 32-byte record per
-//              pixel-sample and advances the RNG counters.  This is the only sequential chain.
-//   k_shadow   over all S x chunks units at once: lights, shadow rays, radiance of the sample.
-//   k_accum    per pixel, in sample order: the running mean of kernel.cu:65-66,75,77.
-// k_shadow of one batch overlaps k_primary of the next on a second stream; a step is then
-// as long as its throughput allows, not spp times its costliest chunk (Multi-GPU).
+// next iteration).  The shadow rays -- most of the work -- do not feed back into it, and the
+// count itself rarely changes from one sample of a pixel to the next.  So, per batch of S
+// samples (16, or 32), a wave working on px pixels x ss samples = 128 rays:
+//   k_primary       camera rays of all samples at once from PREDICTED counters, checked
+//                   afterwards; one 32-byte hit record per pixel-sample
+//   k_primary_hard  the few pixels the prediction fails on, by enumeration of their counters
+//   k_shadow        lights, shadow rays, radiance of every sample, and the pixels' running
+//                   mean in sample order (kernel.cu:65-66,75,77)
+// k_shadow of one batch overlaps k_primary of the next on a second stream; a step is as
+// long as its throughput allows, not spp times its costliest chunk (Multi-GPU).
 struct BatchArgs {
     DevView v;
     TravArgs T;
@@ -852,6 +854,7 @@ struct BatchArgs {
     uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2): fixes the record layout
     uint4 *hard_q;                   // k_primary -> k_primary_hard: (pixel, first open sample, its counter, -)
     uint32_t *hard_cnt;              // [0] entries queued, [1] entries taken
+    int cnt0;                        // k_shadow: samples accumulated before this batch
     bool occlusion;
     Ctl *ctl;
 };
@@ -1207,10 +1210,9 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
         }
         S[h].le = mk3(0.0f, 0.0f, 0.0f);
     }
-    if (!__ballot(hit[0] | hit[1]))
-        return;
     RayPair w;
-    for (int j = 0; j < L; j++) {
+    const int n_lights = __ballot(hit[0] | hit[1]) ? L : 0;  // nobody hit: nothing to light
+    for (int j = 0; j < n_lights; j++) {
         // one point light against the hits: Scene.cu:83-120 -> evaluateDirectLight :205-224
         const LightRec light = load_uniform(&v.lights[j]);
         v3 so[2], sd[2];
@@ -1266,13 +1268,47 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
                 S[h].le = add(S[h].le, S[h].contrib);
         }
     }
+    v3 res[2];
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-        if (hit[h]) {
-            // PathTracer.cu:73 with beta = 1, res = 0
-            v3 res = add(mk3(0.0f, 0.0f, 0.0f), mul(mk3(1.0f, 1.0f, 1.0f), S[h].le));
-            A.b.f[0][idx[h]] = res.x; A.b.f[1][idx[h]] = res.y; A.b.f[2][idx[h]] = res.z;
+    for (int h = 0; h < 2; h++)                              // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64)
+        res[h] = hit[h] ? add(mk3(0.0f, 0.0f, 0.0f), mul(mk3(1.0f, 1.0f, 1.0f), S[h].le)) : mk3(0.0f, 0.0f, 0.0f);
+    // kernel.cu:65-66,75,77: the running mean of each pixel, in sample order.  The wave holds all
+    // samples of its pixels; lane q < px owns pixel q and pulls sample s from the lane that has it.
+    if (px_log2 == 7u) {                                     // one sample: both pixels of a lane
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t pl = (unit << 7) + (uint32_t)h * 64u + lane;
+            if (pl < A.n && A.n_samples) {
+                const int cnt = A.cnt0 + 1;
+                const float frac1 = 1.0f / cnt, frac2 = frac1 * (cnt - 1);
+                float4 prev = v.fb[pl];
+                prev.x = frac2 * prev.x + frac1 * res[h].x;
+                prev.y = frac2 * prev.y + frac1 * res[h].y;
+                prev.z = frac2 * prev.z + frac1 * res[h].z;
+                prev.w = 1.0f;
+                v.fb[pl] = prev;
+            }
         }
+    } else {
+        const uint32_t pl = (unit << px_log2) + lane;
+        const bool owner = lane <= px_mask && pl < A.n;
+        float4 prev = owner ? v.fb[pl] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t smp = 0; smp < A.n_samples; smp++) {
+            const uint32_t r = (smp << px_log2) + (lane & px_mask);
+            const bool upper = (smp << px_log2) >= 64u;      // wave-uniform
+            const float rx = __shfl(upper ? res[1].x : res[0].x, (int)(r & 63u));
+            const float ry = __shfl(upper ? res[1].y : res[0].y, (int)(r & 63u));
+            const float rz = __shfl(upper ? res[1].z : res[0].z, (int)(r & 63u));
+            const int cnt = A.cnt0 + (int)smp + 1;
+            const float frac1 = 1.0f / cnt, frac2 = frac1 * (cnt - 1);
+            prev.x = frac2 * prev.x + frac1 * rx;
+            prev.y = frac2 * prev.y + frac1 * ry;
+            prev.z = frac2 * prev.z + frac1 * rz;
+            prev.w = 1.0f;
+        }
+        if (owner)
+            v.fb[pl] = prev;
+    }
     if (lane == 0 && n_shadow)
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
 }
@@ -1293,30 +1329,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_
         (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, lane, st); },
         [&](uint32_t) {});
-}
-
-// kernel.cu:65-66,75,77 for the S samples of a batch, in sample order; cnt0 = samples
-// accumulated before the batch.  A miss contributes res = 0 (PathTracer.cu:64).
-__global__ void k_accum(SampleBatch b, float4 *__restrict__ fb, uint32_t n, uint32_t n_samples,
-                        uint32_t ss_log2, int cnt0)
-{
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n)
-        return;
-    float4 prev = fb[p];
-    for (uint32_t s = 0; s < n_samples; s++) {
-        const size_t i = rec_index(ss_log2, p, s);
-        const bool hit = __float_as_int(b.f[7][i]) >= 0;
-        const float rx = hit ? b.f[0][i] : 0.0f, ry = hit ? b.f[1][i] : 0.0f, rz = hit ? b.f[2][i] : 0.0f;
-        const int cnt = cnt0 + (int)s + 1;
-        float frac1 = 1.0f / cnt;
-        float frac2 = frac1 * (cnt - 1);
-        prev.x = frac2 * prev.x + frac1 * rx;
-        prev.y = frac2 * prev.y + frac1 * ry;
-        prev.z = frac2 * prev.z + frac1 * rz;
-        prev.w = 1.0f;
-    }
-    fb[p] = prev;
 }
 
 // ------------------------------------------------------------------ Scene::hit on a ray queue
@@ -1572,25 +1584,19 @@ void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samp
 }
 
 void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                   const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
+                   const SampleBatch &b, int cnt0, int max_blocks, Ctl *ctl, uint32_t *work,
                    uint32_t *work_next)
 {
     if (n == 0 || n_samples == 0)
         return;
     BatchArgs A = batch_args(v, n, n_samples, b, ctl);
+    A.cnt0 = cnt0;
     const int dynamic = v.cull && v.tree.top >= 3;
     const uint32_t px = kPathChunk >> A.ss_log2;
     const unsigned long long units = (n + px - 1) / px;
     const uint32_t g = batch_grid((uint32_t)units, (uint32_t)std::max(max_blocks, 1) * 4u);
     if (v.cull) k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     else        k_shadow<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-}
-
-void launch_accum(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                  const SampleBatch &b, int cnt0)
-{
-    if (n && n_samples)
-        k_accum<<<(n + 255) / 256, 256, 0, s>>>(b, v.fb, n, n_samples, batch_ss_log2(n_samples), cnt0);
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

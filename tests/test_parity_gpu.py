@@ -205,7 +205,8 @@ def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
     RNG counters and settles mispredicted pixels by enumeration (k_primary, k_primary_hard).
     Batches are of 16 samples, of 32 from 64 samples on (70 = 32 + 32 + 6).
     On a scene built to defeat the prediction it must equal (a) the oracle, (b) the same
-    samples rendered one call at a time, (c) the unculled per-sample path kernel -- in every
+    samples rendered one call at a time or in uneven calls, (c) the unculled per-sample path
+    kernel -- in every
     bit of image, id and t buffers, and in the ray counts."""
     scene = flicker_scene(np.random.default_rng(31), 3000)
     cam = CameraArgs.for_image(80, 48, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
@@ -213,19 +214,23 @@ def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
     ctx.upload_scene(scene)
     ctx.set_camera(cam)
     out, stats = [], []
-    for mode in ("batched", "one by one", "scan"):
+    for mode in ("batched", "one by one", "scan", "uneven calls"):
         ctx.set_culling(0 if mode == "scan" else 1)
         ctx.reset()
         ctx.reset_stats()
         if mode == "one by one":
             for _ in range(spp):
                 ctx.render(1, 0)
+        elif mode == "uneven calls":                    # batches of 5, 3 and the rest (16s / 32s + remainder)
+            ctx.render(5, 0)
+            ctx.render(3, 0)
+            ctx.render(spp - 8, 0)
         else:
             ctx.render(spp, 0)
         out.append(ctx.read_framebuffer())
         stats.append(ctx.stats())
     ctx.set_culling(1)
-    for other in (1, 2):
+    for other in (1, 2, 3):
         for k in ("rgba", "t", "prim_id"):
             assert np.array_equal(out[0][k].view(np.uint32), out[other][k].view(np.uint32)), (other, k)
         assert stats[0].shadow_rays == stats[other].shadow_rays

@@ -21,8 +21,8 @@ hits come from k_primary a batch ahead, `primary_kernel` in the line), over a sh
 one k_path (the whole path of a pixel-sample in one launch).  Algorithmic bytes per
 launch / its mean HIP-event duration (events on the stream the kernel runs on), against
 the 8 TB/s HBM peak.  Unit = one pixel-sample.  Algorithmic bytes per unit (DESIGN.md,
-"Measurement"): k_shadow 44 B = 32-byte hit record read + 12 bytes of radiance written;
-k_path 52 B = framebuffer texel read + write (32), RNG counter read + write (8),
+"Measurement"): k_shadow 32-byte hit record read + the framebuffer texel read and written
+once per batch (32 B / samples of the batch, it keeps the running mean itself); k_path 52 B = framebuffer texel read + write (32), RNG counter read + write (8),
 pixel-map entry (4), id + t buffers (8); plus one pass over the scene records per launch
 (64 B triangle record + 32 B of box tree per triangle, 132 B per sphere).  The figure
 SURVEY 8(d) defined for a plain scan (every ray streams every triangle, one fetch shared
@@ -49,7 +49,8 @@ SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
 RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out per ray
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
-SHADOW_UNIT_BYTES = 44.0     # k_shadow: 32 B hit record read + 12 B radiance written per pixel-sample
+SHADOW_RECORD_BYTES = 32.0   # k_shadow: hit record read per pixel-sample
+SHADOW_PIXEL_BYTES = 32.0    # k_shadow: fb texel read + written once per pixel per launch
 
 
 def parse():
@@ -208,11 +209,13 @@ def main():
         # = pixel-samples.
         pipeline = st.primary_launches > 0
         kernel = "k_shadow" if pipeline else "k_path"
-        unit_bytes = SHADOW_UNIT_BYTES if pipeline else PIXEL_SAMPLE_BYTES
         rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
         launches = max(1, st.path_launches)
         k_ms = st.path_ms / launches
         units_per_launch = float(st.samples) / launches
+        n_pixels_rank = float(st.samples) / max(1, spp * a.steps)   # stats cover the timed steps
+        unit_bytes = (SHADOW_RECORD_BYTES + SHADOW_PIXEL_BYTES * n_pixels_rank / max(units_per_launch, 1.0)
+                      if pipeline else PIXEL_SAMPLE_BYTES)
         rays_per_launch = (float(st.shadow_rays) if pipeline else rays_k) / launches
         bytes_per_launch = (unit_bytes * units_per_launch + n_tri * TRI_REC_BYTES
                             + n_sph * SPH_BYTES)

@@ -1024,9 +1024,11 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
         PrimaryTrace o;
         trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, st);
         uint32_t q[2], smp[2], p[2];
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const uint32_t r = (uint32_t)h * 64u + lane;
+            const uint32_t r = (uint32_t)h * 64u + ln;
             q[h] = r & px_mask;
             smp[h] = r >> px_log2;
             p[h] = min((unit << px_log2) + q[h], A.n - 1u);

@@ -78,7 +78,7 @@ struct rt_context {
     hipEvent_t ev_prim_done[2] = {nullptr, nullptr}, ev_shade_done[2] = {nullptr, nullptr};
     SampleBatch batch[2]{};
     uint32_t batch_cap = 0;              // samples per record buffer
-    int batch_wanted = 32;
+    int batch_wanted = 64;
     uint64_t primary_launches = 0;
     double primary_ms = 0.0;
     std::vector<hipEvent_t> ev_pool2;    // (start, stop) pairs around k_primary launches
@@ -425,7 +425,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
                  hipEventCreateWithFlags(&c->ev_shade_done[b], hipEventDisableTiming) == hipSuccess;
         if (!ok) rc = fail(c, RT_ERR_DEVICE, "rt_create: could not create pipeline streams");
     }
-    if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(32, std::atoi(e)));
+    if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(64, std::atoi(e)));
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -577,9 +577,9 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
         // the accumulation on a second one, a batch behind (rt_kernels.hip, "depth 0 in
         // three kernels").  Two record buffers alternate; a buffer is refilled only after
         // its shadow pass has finished.
-        // batches of 32 samples when that still leaves two to overlap, else of 16
-        const uint32_t cap = (uint32_t)std::min(std::max(n_samples, 1),
-                                                n_samples >= 64 ? c->batch_wanted : std::min(c->batch_wanted, 16));
+        // the largest batch (64, 32, 16 samples) that still leaves two batches to overlap
+        const int want = n_samples >= 128 ? 64 : n_samples >= 64 ? 32 : 16;
+        const uint32_t cap = (uint32_t)std::min(std::max(n_samples, 1), std::min(c->batch_wanted, want));
         int rc = ensure_batches(c, cap);
         if (rc) return rc;
         hipStream_t sa = c->whole.stream, sb = c->st_shade;

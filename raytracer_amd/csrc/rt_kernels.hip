@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
 }
 
 // One unit = 128 pixel-samples = px consecutive pixels (a compact patch of the image) x ss
-// consecutive samples of the batch, ss = 2^ss_log2 <= 32: the shadow rays of one pixel's
+// consecutive samples of the batch, ss = 2^ss_log2 <= 64: the shadow rays of one pixel's
 // samples towards a light differ only by the sub-pixel jitter, so packing samples instead of
 // more pixels into a wave shrinks the part of the tree the wave's rays visit together
 // (16 samples x 8 pixels against 1 x 128: C3 -27 % shadow time, C4 -40 %, C5 -68 %).
@@ -1531,11 +1531,11 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     }
 }
 
-// Samples a wave holds: the smallest power of two that takes the whole batch (<= 32).
+// Samples a wave holds: the smallest power of two that takes the whole batch (<= 64).
 static uint32_t batch_ss_log2(uint32_t n_samples)
 {
     uint32_t l = 0;
-    while (l < 5u && (1u << l) < n_samples) l++;
+    while (l < 6u && (1u << l) < n_samples) l++;
     return l;
 }
 

@@ -199,11 +199,12 @@ def flicker_scene(rng, n_tris):
     return b.build()
 
 
-@pytest.mark.parametrize("spp", [16, 21, 70])
+@pytest.mark.parametrize("spp", [16, 21, 70, 140])
 def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
     """rt_render(n, 0) over a deep tree traces all samples of a batch at once from PREDICTED
     RNG counters and settles mispredicted pixels by enumeration (k_primary, k_primary_hard).
-    Batches are of 16 samples, of 32 from 64 samples on (70 = 32 + 32 + 6).
+    Batches are of 16 samples, of 32 from 64 samples on (70 = 32 + 32 + 6), of 64 from 128 on
+    (140 = 64 + 64 + 12).
     On a scene built to defeat the prediction it must equal (a) the oracle, (b) the same
     samples rendered one call at a time or in uneven calls, (c) the unculled per-sample path
     kernel -- in every

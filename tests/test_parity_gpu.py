@@ -242,6 +242,34 @@ def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
         check_images(out[0], ref, stats[0])
 
 
+def test_sample_batches_with_spheres_and_ties(gpu_ctx_factory):
+    """The batch kernels over the triangle soup (exact duplicates, slivers, invisible triangles)
+    plus two quadric spheres: 18 samples at depth 0 against the oracle and against the unculled
+    path kernel."""
+    scene = soup_scene(np.random.default_rng(23), 1500)
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    ctx = gpu_ctx_factory(96, 64)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    ctx.set_timing(True)                                  # launch counts come with the timing events
+    out, stats = [], []
+    for cull in (1, 0):
+        ctx.set_culling(cull)
+        ctx.reset()
+        ctx.reset_stats()
+        ctx.render(18, 0)
+        out.append(ctx.read_framebuffer())
+        stats.append(ctx.stats())
+    ctx.set_culling(1)
+    ctx.set_timing(False)
+    assert stats[0].primary_launches > 0 and stats[1].primary_launches == 0   # batch kernels vs path kernel
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    ref = orc.render(scene, cam, 96, 64, spp=18, max_depth=0)
+    check_images(out[0], ref, stats[0])
+    assert (out[0]["prim_id"] >= scene.n_tris).any()                          # a sphere is visible
+
+
 @pytest.mark.parametrize("depth,spp", [(0, 1), (0, 3), (12, 2)])
 def test_c1_sphere(gpu_ctx_factory, depth, spp):
     cfg = scenes.c1(160, 120)

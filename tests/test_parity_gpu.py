@@ -242,6 +242,26 @@ def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
         check_images(out[0], ref, stats[0])
 
 
+@pytest.mark.parametrize("batch", ["1", "5", "64"])
+def test_batch_size_does_not_change_the_image(gpu_ctx_factory, monkeypatch, batch):
+    """RT_BATCH (read at rt_create) caps the samples per batch; any cap gives the same bits."""
+    scene = flicker_scene(np.random.default_rng(37), 2000)
+    cam = CameraArgs.for_image(64, 40, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    out = []
+    for env in (None, batch):
+        if env is None:
+            monkeypatch.delenv("RT_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("RT_BATCH", env)
+        ctx = gpu_ctx_factory(64, 40)
+        ctx.upload_scene(scene)
+        ctx.set_camera(cam)
+        ctx.render(130, 0)
+        out.append(ctx.read_framebuffer())
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+
+
 def test_sample_batches_with_spheres_and_ties(gpu_ctx_factory):
     """The batch kernels over the triangle soup (exact duplicates, slivers, invisible triangles)
     plus two quadric spheres: 18 samples at depth 0 against the oracle and against the unculled

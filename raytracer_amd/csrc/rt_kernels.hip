@@ -837,7 +837,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
 // (Scene.cu:87) + 1 if the BRDF sample is usable (PathTracer.cu:77, the discarded trace of the
 // next iteration).  The shadow rays -- most of the work -- do not feed back into it, and the
 // count itself rarely changes from one sample of a pixel to the next.  So, per batch of S
-// samples (16, or 32), a wave working on px pixels x ss samples = 128 rays:
+// samples (16, 32 or 64), a wave working on px pixels x ss samples = 128 rays:
 //   k_primary       camera rays of all samples at once from PREDICTED counters, checked
 //                   afterwards; one 32-byte hit record per pixel-sample
 //   k_primary_hard  the few pixels the prediction fails on, by enumeration of their counters
@@ -872,8 +872,8 @@ __device__ __forceinline__ size_t rec_index(uint32_t ss_log2, uint32_t p, uint32
 // the NUMBER of draws each one consumes: 2 on a miss, 2 + lights on a hit, +1 if the hit's BRDF
 // sample is usable (PathTracer.cu:77) -- and that number is almost always the one of the sample
 // before.  Two kernels:
-//   k_primary  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples; 8 x 16
-//     for a full batch).  Every sample's counter is PREDICTED from its pixel's expected draws
+//   k_primary  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples: 8 x 16,
+//     4 x 32 or 2 x 64).  Every sample's counter is PREDICTED from its pixel's expected draws
 //     per sample (round 0: what the pixel's last sample did; round 1: what the first
 //     mispredicted one did), all are traced together, and the prediction is checked pixel by
 //     pixel: the samples up to and including the first whose draw count differs were traced
@@ -883,10 +883,10 @@ __device__ __forceinline__ size_t rec_index(uint32_t ss_log2, uint32_t p, uint32
 //   k_primary_hard   one queued pixel per wave.  The next 8 samples can only start at the
 //     counters base + 2 a + (2 + lights) b + (3 + lights) c, a + b + c < 8 -- 120 candidates --
 //     so the wave traces ALL of them for the one pixel at once and then walks the chain through
-//     the table: two rounds settle the 15 samples that can be open.
+//     the table: eight samples per round, so two rounds settle a batch of 16, eight one of 64.
 // Every record that is written was computed from the exact counter of the reference's order, so
 // the result is bit-identical to sample-after-sample; only the chain of spp dependent
-// traversals is gone: no pixel needs more than four (Multi-GPU).
+// traversals is gone: no pixel needs more than 2 + ss / 8 (Multi-GPU).
 // What a lane carries across a traversal is parked in LDS (slot i of a lane: st[i * kBlock]),
 // as in the path kernel: the closest-hit traversal needs the register file to itself, and what
 // the compiler would otherwise spill goes to scratch memory and from there to HBM.

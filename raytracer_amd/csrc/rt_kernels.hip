@@ -874,8 +874,8 @@ __device__ __forceinline__ size_t rec_index(uint32_t ss_log2, uint32_t p, uint32
 // before.  Two kernels:
 //   k_primary  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples: 8 x 16,
 //     4 x 32 or 2 x 64).  Every sample's counter is PREDICTED from its pixel's expected draws
-//     per sample (round 0: what the pixel's last sample did; round 1: what the first
-//     mispredicted one did), all are traced together, and the prediction is checked pixel by
+//     per sample (round 0: what the pixel's last sample did; round 1: the same, or what the
+//     mispredicted sample did if that was the pixel's first), all are traced together, and the prediction is checked pixel by
 //     pixel: the samples up to and including the first whose draw count differs were traced
 //     from the counter the sequential order gives them and are final.  Pixels still open
 //     after two rounds flip between outcomes from sample to sample (silhouettes, ~1 % of the
@@ -1061,9 +1061,12 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
                 todo[h] = false;
             }
             if (first[h] < ss) {                             // the pixel goes on from behind sample `first`
+                // ... expecting what it expected before, unless its very first open sample
+                // was the odd one (then the pixel as a whole has changed: expect that instead)
+                const bool changed = first[h] == base_s[h];
                 base_c[h] += (first[h] - base_s[h]) * dhat[h] + dj;
                 base_s[h] = first[h] + 1u;
-                dhat[h] = dj;
+                dhat[h] = changed ? dj : dhat[h];
             }
             // still open after the second round: the lane of a pixel's first open sample queues the pixel
             if (round == 1 && todo[h] && smp[h] == base_s[h]) {

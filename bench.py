@@ -225,7 +225,7 @@ def main():
         scan_gbs = scan_per_ray * (rays_total / a.steps) / (dt / a.steps) / 1e9 if dt > 0 else 0.0
         tests = rays_k * (n_tri + n_sph)
         out = {
-            "metric": "Mrays/sec (primary+shadow) at 1080p",
+            "metric": f"Mrays/sec (primary+shadow) at {cfg.height}p",
             "value": rays_total / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,

@@ -91,6 +91,8 @@ typedef struct rt_stats {
     uint64_t streams;        /* HIP streams the partition's pixel ranges render on   */
     uint64_t primary_launches; /* launches of k_primary (max_depth 0), timing mode only */
     double primary_ms;       /* their summed HIP-event duration                       */
+    uint64_t coop_chunks;    /* k_path chunks run in the cooperative form (four waves sharing the
+                                traversals of one chunk; max_depth > 0 over a deep tree)        */
 } rt_stats;
 
 /* Replaces the surface/graph set-up of initCUDA (kernel.cu:193-256): creates the

@@ -716,8 +716,36 @@ int orc_num_threads(void)
 #endif
 }
 
-/* kernel.cu:50-79 `debug`, with the H4 conventions: jitter = (.x,.y) of one
+/* kernel.cu:50-79 `debug` for one pixel, with the H4 conventions: jitter = (.x,.y) of one
  * uniform4 from the pixel's own stream, cnt = 1-based sample index. */
+static void render_pixel(const orc_scene *scene, const cam_t *cam, int width, int height, int x,
+                         int y, int spp, int max_depth, float *rgba, int32_t *prim_id,
+                         float *t_out, orc_counts *c)
+{
+    rng_t g = { (uint32_t)(y * width + x), 0u };                    /* kernel.cu:46-47 */
+    f3 px = mk3(0.0f, 0.0f, 0.0f);
+    float ft = ORC_INF;
+    int fprim = -1;
+    for (int cnt = 1; cnt <= spp; cnt++) {
+        float frac1 = 1.0f / cnt;                                   /* :65 */
+        float frac2 = frac1 * (cnt - 1);                            /* :66 */
+        float j[4];
+        rng_uniform4(&g, j);                                        /* :67 (H4) */
+        float xoff = j[0], yoff = j[1];
+        ray_t r = cam_generate_ray(cam, x - width / 2 + xoff, y - height / 2 + yoff);    /* :73 */
+        f3 col = path_tracer(scene, r, &g, max_depth, c, &ft, &fprim);                   /* :74 */
+        px = add3(scale3(px, frac2), scale3(col, frac1));           /* :75 */
+    }
+    if (rgba) {
+        rgba[0] = px.x;
+        rgba[1] = px.y;
+        rgba[2] = px.z;
+        rgba[3] = 1.0f;                                             /* :77 */
+    }
+    if (prim_id) *prim_id = fprim;
+    if (t_out) *t_out = ft;
+}
+
 int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int width, int height,
                int x0, int y0, int x1, int y1, int spp, int max_depth, int threads,
                float *rgba, int32_t *prim_id, float *t_out, orc_counts *counts)
@@ -734,32 +762,52 @@ int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int widt
 #else
     (void)threads;
 #endif
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : n_primary, n_shadow, n_bounce)
+    /* small windows over big meshes: one pixel per task, or most threads would idle */
+    const int grain = cw * ch >= 4096 ? 16 : 1;
+#pragma omp parallel for schedule(dynamic, grain) reduction(+ : n_primary, n_shadow, n_bounce)
     for (int i = 0; i < cw * ch; i++) {
-        int x = x0 + i % cw, y = y0 + i / cw;
-        rng_t g = { (uint32_t)(y * width + x), 0u };                /* kernel.cu:46-47 */
-        f3 px = mk3(0.0f, 0.0f, 0.0f);
-        float ft = ORC_INF;
-        int fprim = -1;
         orc_counts c = { 0, 0, 0 };
-        for (int cnt = 1; cnt <= spp; cnt++) {
-            float frac1 = 1.0f / cnt;                               /* :65 */
-            float frac2 = frac1 * (cnt - 1);                        /* :66 */
-            float j[4];
-            rng_uniform4(&g, j);                                    /* :67 (H4) */
-            float xoff = j[0], yoff = j[1];
-            ray_t r = cam_generate_ray(&cam, x - width / 2 + xoff, y - height / 2 + yoff); /* :73 */
-            f3 col = path_tracer(scene, r, &g, max_depth, &c, &ft, &fprim);             /* :74 */
-            px = add3(scale3(px, frac2), scale3(col, frac1));       /* :75 */
-        }
-        if (rgba) {
-            rgba[4 * i + 0] = px.x;
-            rgba[4 * i + 1] = px.y;
-            rgba[4 * i + 2] = px.z;
-            rgba[4 * i + 3] = 1.0f;                                 /* :77 */
-        }
-        if (prim_id) prim_id[i] = fprim;
-        if (t_out) t_out[i] = ft;
+        render_pixel(scene, &cam, width, height, x0 + i % cw, y0 + i / cw, spp, max_depth,
+                     rgba ? rgba + 4 * i : NULL, prim_id ? prim_id + i : NULL,
+                     t_out ? t_out + i : NULL, &c);
+        n_primary += c.primary;
+        n_shadow += c.shadow;
+        n_bounce += c.bounce;
+    }
+    if (counts) {
+        counts->primary = n_primary;
+        counts->shadow = n_shadow;
+        counts->bounce = n_bounce;
+    }
+    return 0;
+}
+
+/* The same for an explicit list of pixels (xy[2 i], xy[2 i + 1]): what the full-size parity
+ * tests use to check a handful of pixels of a 4K frame over a mesh of millions of triangles
+ * with every host thread busy. */
+int orc_render_pixels(const orc_scene *scene, const orc_camera_args *cam_args, int width,
+                      int height, int n, const int32_t *xy, int spp, int max_depth, int threads,
+                      float *rgba, int32_t *prim_id, float *t_out, orc_counts *counts)
+{
+    if (!scene || !cam_args || n < 0 || (n > 0 && !xy) || spp < 1)
+        return -1;
+    for (int i = 0; i < n; i++)
+        if (xy[2 * i] < 0 || xy[2 * i] >= width || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= height)
+            return -1;
+    cam_t cam = cam_make(cam_args);
+    uint64_t n_primary = 0, n_shadow = 0, n_bounce = 0;
+#ifdef _OPENMP
+    if (threads > 0)
+        omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_primary, n_shadow, n_bounce)
+    for (int i = 0; i < n; i++) {
+        orc_counts c = { 0, 0, 0 };
+        render_pixel(scene, &cam, width, height, xy[2 * i], xy[2 * i + 1], spp, max_depth,
+                     rgba ? rgba + 4 * i : NULL, prim_id ? prim_id + i : NULL,
+                     t_out ? t_out + i : NULL, &c);
         n_primary += c.primary;
         n_shadow += c.shadow;
         n_bounce += c.bounce;

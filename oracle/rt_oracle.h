@@ -11,7 +11,7 @@
  * this image without hand-written stand-ins for cuda_runtime.h / curand_kernel.h /
  * libcudart, which the build rules forbid.  The only outputs of the reference
  * itself that exist are the three known answers the surveyor recorded from the
- * reference's own code; tests/test_oracle_pins.py checks
+ * reference's own code; tests/test_oracle_cpu.py::test_survey_known_answer checks
  * this restatement against the one that is fully specified (sphere + point light,
  * 64x48, centre pixel: t = 5.005611, radiance (0.244406, 0.010100, 0.011608)).
  * Everything else is "parity unpinned": the oracle is a line-by-line restatement
@@ -89,6 +89,13 @@ int orc_render(const orc_scene *scene, const orc_camera_args *cam,
                int width, int height, int x0, int y0, int x1, int y1,
                int spp, int max_depth, int threads,
                float *rgba, int32_t *prim_id, float *t, orc_counts *counts);
+
+/* The same for an explicit list of n pixels xy[n][2] = (x, y); outputs are [n][4] / [n] / [n].
+ * One OpenMP task per pixel: a handful of pixels over a mesh of millions of triangles keeps
+ * every thread busy. */
+int orc_render_pixels(const orc_scene *scene, const orc_camera_args *cam, int width, int height,
+                      int n, const int32_t *xy, int spp, int max_depth, int threads,
+                      float *rgba, int32_t *prim_id, float *t, orc_counts *counts);
 
 /* Scene::hit on explicit rays (Scene/Scene.cu:8-67).  dir is normalised by the
  * Ray constructor exactly as the reference does (Ray/Ray.cu:2).

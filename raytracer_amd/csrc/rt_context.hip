@@ -51,6 +51,7 @@ struct rt_context {
     std::vector<void *> allocs;          // everything freed by rt_destroy
     std::vector<void *> scene_allocs;    // freed on re-upload
     std::vector<void *> part_allocs;     // freed on re-partition
+    std::vector<void *> batch_allocs;    // record buffers of the depth-0 pipeline: freed when outgrown or on re-partition
 
     int rank = 0, world = 1, tile = 64;
     uint32_t n_local = 0;
@@ -195,6 +196,7 @@ int alloc_feedback(rt_context *c, Lane &L)
 int setup_partition(rt_context *c)
 {
     free_all(c->part_allocs);
+    free_all(c->batch_allocs);
     build_pixmap(c);
     const size_t n = c->n_local;
     DevView &v = c->v;
@@ -240,7 +242,9 @@ int setup_partition(rt_context *c)
     return RT_OK;
 }
 
-// Record buffers of the depth-0 pipeline for batches of up to `cap` samples.
+// Record buffers of the depth-0 pipeline for batches of up to `cap` samples.  A set that has
+// been outgrown is freed before the larger one is allocated (the streams are idle here: every
+// rt_render ends with a synchronisation), and so is a set whose allocation failed half way.
 int ensure_batches(rt_context *c, uint32_t cap)
 {
     if (cap <= c->batch_cap) return RT_OK;
@@ -255,10 +259,15 @@ int ensure_batches(rt_context *c, uint32_t cap)
         c->batch[1].hard_q = c->batch[0].hard_q;
         c->batch[1].hard_cnt = c->batch[0].hard_cnt;
     }
+    free_all(c->batch_allocs);
+    c->batch_cap = 0;
     for (int b = 0; b < 2; b++) {
         for (int k = 0; k < 8; k++) {
-            int rc = dalloc(c, c->part_allocs, c->batch[b].f[k], n);   // outgrown ones stay until re-partition
-            if (rc) return rc;
+            int rc = dalloc(c, c->batch_allocs, c->batch[b].f[k], n);
+            if (rc) {
+                free_all(c->batch_allocs);
+                return rc;
+            }
         }
     }
     c->batch_cap = cap;
@@ -442,6 +451,7 @@ extern "C" int rt_destroy(rt_context *c)
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_all(c->batch_allocs);
     free_all(c->part_allocs);
     free_all(c->scene_allocs);
     free_all(c->allocs);
@@ -513,7 +523,7 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     c->geom_extent = hs.geom_extent;
     update_extent(c);
     c->n_lights = v.n_lights;
-    c->n_prims = (uint64_t)hs.tris.size() + hs.spheres.size();
+    c->n_prims = (uint64_t)hs.cold.size() + hs.spheres.size();   // hs.tris is padded to whole groups
     c->have_scene = true;
     return RT_OK;
 }
@@ -795,7 +805,7 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
 {
     if (!c || !st) return fail(c, RT_ERR_INVALID, "NULL argument");
     RT_HIP(c, hipSetDevice(c->device));
-    unsigned long long shadow_total = 0, bounce_total = 0;
+    unsigned long long shadow_total = 0, bounce_total = 0, coop_total = 0;
     std::vector<Ctl *> ctls;
     for (int k = 0; k < c->n_lanes; k++) ctls.push_back(c->lanes[k].ctl);
     ctls.push_back(c->whole.ctl);
@@ -805,6 +815,7 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
         RT_HIP(c, hipMemcpy(&h, p, sizeof(Ctl), hipMemcpyDeviceToHost));
         shadow_total += h.shadow_total;
         bounce_total += h.bounce_total;
+        coop_total += h.coop_total;
     }
     st->samples = c->samples;
     st->primary_rays = c->primary;
@@ -817,6 +828,7 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->streams = (uint64_t)c->n_lanes;
     st->primary_launches = c->primary_launches;
     st->primary_ms = c->primary_ms;
+    st->coop_chunks = coop_total;
     return RT_OK;
 }
 

@@ -18,6 +18,7 @@ struct Ctl {
     uint32_t work[2][kWorkSlots];
     unsigned long long shadow_total;   // shadow rays cast since rt_reset_stats
     unsigned long long bounce_total;   // bounce (>= 1) rays traced since rt_reset_stats
+    unsigned long long coop_total;     // chunks run in the cooperative (four-wave) form since rt_reset_stats
 };
 
 constexpr int kWorkHeavy = 8, kWorkEarly = 9;

@@ -713,6 +713,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
     if (lane == 0) {
         if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
         if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
+        if (COOP) atomicAdd(&A.ctl->coop_total, 1ull);
         if (env.feedback)
             record_cost(A.fb, env, chunk, cost);
     }
@@ -1508,14 +1509,12 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
     if (fb) A.fb = *fb;
     const bool d0 = max_depth == 0;
-    // Waves per SIMD (measured on MI355X, whole frames and 1/2 .. 1/8 partitions): a tree far
-    // larger than an XCD's 4 MB L2 (C4: 871 k triangles = 84 MB of records) waits on memory at
-    // almost every step and wants four; a shallow tree (cheap, uniform chunks) three; a tree
-    // that mostly sits in L2 (C3: 69 k triangles) is bound by VALU issue and by its longest
-    // chunks, which run fastest at two.  The grid is what is resident at once.
+    // Waves per SIMD the register allocation aims at.  Depth 0 with culling reaches this kernel
+    // only over a shallow tree (deeper ones take the batch pipeline, rt_context.hip): cheap,
+    // uniform chunks, three waves per SIMD measured best (C2: +17 % over two).  With bounces
+    // the per-bounce state wants the registers: two.  The grid is what is resident at once.
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
-    int waves = 2;
-    if (d0 && v.cull) waves = v.n_tris >= 200000 ? 4 : (dynamic ? 2 : 3);
+    const int waves = (d0 && v.cull) ? 3 : 2;
     const uint32_t g = grid_for_chunks(n, max_blocks * waves);
     // Cooperative form from which multiple of the mean chunk cost on: a launch with many
     // chunks per resident wave is throughput-bound, and sharing a chunk among four waves
@@ -1524,10 +1523,8 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves * (kBlock / 64);
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
     if (v.cull) {
-        if (!d0)             k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else if (waves == 4) k_path<true, true, 4><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else if (waves == 3) k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else                 k_path<true, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        if (!d0) k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else     k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     } else {
         if (d0) k_path<false, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else    k_path<false, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
@@ -1578,13 +1575,11 @@ void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samp
     const uint32_t cap = (uint32_t)std::max(max_blocks, 1) * 4u;
     (void)hipMemsetAsync(A.hard_cnt, 0, 2 * sizeof(uint32_t), s);
     const uint32_t g = batch_grid(units, cap);
-    if (v.cull) k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-    else        k_primary<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);   // the pipeline runs with culling only (rt_render)
     // the pixels it queued, one per wave (about 1 % of them, at silhouettes; the other waves leave at once)
     if (n_samples > 1u) {
         const uint32_t gh = std::min<uint32_t>(std::max<uint32_t>((n + 31u) / 32u, 1u), cap);
-        if (v.cull) k_primary_hard<true><<<gh, kBlock, 0, s>>>(A);
-        else        k_primary_hard<false><<<gh, kBlock, 0, s>>>(A);
+        k_primary_hard<true><<<gh, kBlock, 0, s>>>(A);
     }
 }
 
@@ -1600,8 +1595,7 @@ void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_sampl
     const uint32_t px = kPathChunk >> A.ss_log2;
     const unsigned long long units = (n + px - 1) / px;
     const uint32_t g = batch_grid((uint32_t)units, (uint32_t)std::max(max_blocks, 1) * 4u);
-    if (v.cull) k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-    else        k_shadow<false><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+    k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

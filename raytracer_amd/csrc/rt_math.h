@@ -153,8 +153,8 @@ constexpr int kMatSpecularBit = 4;          // Material/Object.cuh:10
 //   n     = cross(a - c, b - c)                (:97)
 //   dn    = dot(a, n)                          (:102, second term)
 //   S     = 2.0f * area()                      (:106, :413-420)
-// The records are stored in TRAVERSAL-TREE order (rt_upload.cpp: Morton order of the
-// bounding-sphere centres); `orig` is the triangle's index in the reference's own
+// The records are stored in TRAVERSAL-TREE order (rt_upload.cpp build_tree: recursive rank
+// partition of the leaf boxes' centres); `orig` is the triangle's index in the reference's own
 // traversal order (Scene.cu:13-41), which is what the id buffer reports and what
 // breaks exact ties in t (hazard H8: the reference keeps the first one).
 //   qmax  = upper bound on any |cross|^2 of Model.cu:107-109 for which the area test

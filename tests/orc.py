@@ -36,6 +36,10 @@ def lib():
         L.orc_render.argtypes = [C.POINTER(SceneDesc), C.POINTER(CameraDesc)] + [C.c_int] * 9 + \
             [FP, IP, FP, C.POINTER(Counts)]
         L.orc_render.restype = C.c_int
+        L.orc_render_pixels.argtypes = [C.POINTER(SceneDesc), C.POINTER(CameraDesc), C.c_int, C.c_int,
+                                        C.c_int, IP, C.c_int, C.c_int, C.c_int, FP, IP, FP,
+                                        C.POINTER(Counts)]
+        L.orc_render_pixels.restype = C.c_int
         L.orc_scene_hit.argtypes = [C.POINTER(SceneDesc), C.c_int, FP, FP, FP, IP, IP]
         L.orc_camera_ray.argtypes = [C.POINTER(CameraDesc), C.c_int, FP, FP, FP]
         L.orc_trace_ray.argtypes = [C.POINTER(SceneDesc), FP, FP, C.c_int, C.c_uint32, C.c_uint32,
@@ -77,6 +81,22 @@ def render(scene: SceneData, cam: CameraArgs, width, height, spp=1, max_depth=0,
         raise RuntimeError(f"orc_render failed: {rc}")
     return dict(rgba=rgba, prim_id=pid, t=t, primary=cnt.primary, shadow=cnt.shadow,
                 bounce=cnt.bounce)
+
+
+def render_pixels(scene: SceneData, cam: CameraArgs, width, height, xy, spp=1, max_depth=0, threads=0):
+    """The pixels xy[n, 2] = (x, y) of a width x height frame -> dict(rgba[n,4], prim_id[n], t[n], ...)."""
+    xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+    n = xy.shape[0]
+    rgba = np.zeros((n, 4), np.float32)
+    pid = np.zeros(n, np.int32)
+    t = np.zeros(n, np.float32)
+    cnt = Counts()
+    sd, cd = scene.desc(), CameraDesc.from_args(cam)
+    rc = lib().orc_render_pixels(C.byref(sd), C.byref(cd), width, height, n, _ip(xy), spp, max_depth,
+                                 threads, _fp(rgba), _ip(pid), _fp(t), C.byref(cnt))
+    if rc != 0:
+        raise RuntimeError(f"orc_render_pixels failed: {rc}")
+    return dict(rgba=rgba, prim_id=pid, t=t, primary=cnt.primary, shadow=cnt.shadow, bounce=cnt.bounce)
 
 
 def scene_hit(scene: SceneData, org, dir):

@@ -86,7 +86,7 @@ def test_scene_hit_mixed(gpu_ctx_factory):
 def soup_scene(rng, n_tris):
     """Unordered triangle soup: sizes from invisible (H1) to huge, slivers, duplicates (exact
     ties in t), coplanar pairs; plus two spheres.  Index order is spatially random, so the
-    device order (Morton) differs from the reference order everywhere."""
+    device order (the tree's rank partition) differs from the reference order everywhere."""
     b = SceneBuilder()
     P = []
     for i in range(n_tris):
@@ -114,7 +114,7 @@ def soup_scene(rng, n_tris):
 
 @pytest.mark.parametrize("n_tris,seed", [(5, 11), (300, 12), (4000, 13)])
 def test_culling_is_results_identical(gpu_ctx_factory, n_tris, seed):
-    """Sphere-tree traversal == scan of every triangle == oracle, bit for bit, on a soup
+    """Box-tree traversal == scan of every triangle == oracle, bit for bit, on a soup
     with ties, slivers and invisible triangles; rays from inside and far outside the scene
     (the far ones exceed the culling extent and take the unculled path)."""
     rng = np.random.default_rng(seed)
@@ -158,10 +158,38 @@ def test_culling_render_equals_scan(gpu_ctx_factory):
 
 
 def test_heavy_chunk_feedback_and_cooperative_form(gpu_ctx_factory):
-    """From the third progressive sample on, chunks the previous sample found heavy are
-    handed out first and shared by the four waves of a block (merge by 64-bit min in LDS).
-    Six samples of a deep-tree scene must still match the oracle bit for bit in id / t and
-    the plain scan in every bit of the image."""
+    """The path kernel over a deep tree with bounces (max_depth > 0: the depth-0 pipeline does not
+    apply).  From the second progressive sample on, chunks the previous sample found heavy are
+    handed out first, one per BLOCK, and shared by its four waves (subtrees by hash, hits merged
+    by a 64-bit ds_min in LDS, barriers around every traversal).  rt_stats.coop_chunks proves
+    that form ran.  Six one-sample calls at depth 12 must match the oracle bit for bit in id / t
+    (radiance 1e-4, ray counts equal) and the plain scan in every bit of the image."""
+    cfg = scenes.c3(256, 144, f=12, ground=(10, 6))
+    ctx = gpu_ctx_factory(256, 144)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    out, stats = [], []
+    for cull in (1, 0):
+        ctx.set_culling(cull)
+        ctx.reset()
+        ctx.reset_stats()
+        for _ in range(6):
+            ctx.render(1, 12)
+        out.append(ctx.read_framebuffer())
+        stats.append(ctx.stats())
+    ctx.set_culling(1)
+    assert stats[0].coop_chunks > 0, "no chunk ran in the cooperative form"
+    assert stats[1].coop_chunks == 0                        # the scan has no feedback, hence no heavy chunks
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    assert stats[0].shadow_rays == stats[1].shadow_rays and stats[0].bounce_rays == stats[1].bounce_rays
+    ref = orc.render(cfg.scene, cfg.camera, 256, 144, spp=6, max_depth=12)
+    check_images(out[0], ref, stats[0])
+
+
+def test_depth0_pipeline_on_small_deep_tree(gpu_ctx_factory):
+    """render(2, 0) three times over the same deep tree: the batch pipeline (k_primary ->
+    k_primary_hard -> k_shadow) in batches of two, against the oracle and the plain scan."""
     cfg = scenes.c3(256, 144, f=12, ground=(10, 6))
     ctx = gpu_ctx_factory(256, 144)
     ctx.upload_scene(cfg.scene)
@@ -237,9 +265,10 @@ def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
         assert stats[0].shadow_rays == stats[other].shadow_rays
     hit = out[0]["prim_id"] >= 0
     assert 0.15 < hit.mean() < 0.85                     # the last sample's hits: a coin flip per pixel
-    if spp == 16:
-        ref = orc.render(scene, cam, 80, 48, spp=spp, max_depth=0)
-        check_images(out[0], ref, stats[0])
+    # the oracle at every batch shape: 16 (8 px x 16), 21 = 16 + 5, 70 = 32 + 32 + 6 (4 px x 32,
+    # k_primary_hard's four rounds), 140 = 64 + 64 + 12 (2 px x 64, eight rounds)
+    ref = orc.render(scene, cam, 80, 48, spp=spp, max_depth=0)
+    check_images(out[0], ref, stats[0])
 
 
 @pytest.mark.parametrize("batch", ["1", "5", "64"])
@@ -296,6 +325,16 @@ def test_c1_sphere(gpu_ctx_factory, depth, spp):
     got, ref, st = render_both(gpu_ctx_factory, cfg.scene, cfg.camera, 160, 120, spp, depth)
     check_images(got, ref, st)
     assert (got["prim_id"] >= 0).sum() > 100
+
+
+@pytest.mark.parametrize("depth", [0, 12])
+def test_c1_full_size(gpu_ctx_factory, depth):
+    """C1 as BASELINE.json states it: 640x480, 1 spp, the whole frame against the oracle."""
+    cfg = scenes.c1()
+    assert (cfg.width, cfg.height, cfg.spp) == (640, 480, 1)
+    got, ref, st = render_both(gpu_ctx_factory, cfg.scene, cfg.camera, 640, 480, cfg.spp, depth)
+    check_images(got, ref, st)
+    assert (got["prim_id"] >= 0).sum() > 1000
 
 
 @pytest.mark.parametrize("depth,spp", [(0, 1), (0, 4), (12, 2)])
@@ -488,10 +527,10 @@ def test_full_size_c3(gpu_ctx_factory):
         assert np.array_equal(got[key].view(np.uint32), again[key].view(np.uint32)), key
 
 
-def test_full_size_c4_rays(gpu_ctx_factory):
+def test_full_size_c4_rays(gpu_ctx_factory, c4_full):
     """C4's full mesh (871 414 triangles): Scene::hit with the tree equals the scan of every
     triangle, bit for bit, on camera-like and random rays; a handful of them against the oracle."""
-    cfg = scenes.c4()
+    cfg = c4_full
     ctx = gpu_ctx_factory(64, 64)
     ctx.upload_scene(cfg.scene)
     rng = np.random.default_rng(5)
@@ -515,9 +554,9 @@ def test_full_size_c4_rays(gpu_ctx_factory):
     assert np.array_equal(id1[pick], rid) and np.array_equal(t1[pick].view(np.uint32), rt.view(np.uint32))
 
 
-def test_full_size_c5_rays(gpu_ctx_factory):
+def test_full_size_c5_rays(gpu_ctx_factory, c5_full):
     """C5's 10 M-triangle mesh: tree == scan on rays from the camera and towards the lights."""
-    cfg = scenes.c5()
+    cfg = c5_full
     assert cfg.scene.n_tris == 10_000_000 and cfg.scene.n_lights == 64
     ctx = gpu_ctx_factory(64, 64)
     ctx.upload_scene(cfg.scene)
@@ -540,3 +579,118 @@ def test_full_size_c5_rays(gpu_ctx_factory):
     ctx.set_culling(1)
     assert np.array_equal(id1, id0) and np.array_equal(t1.view(np.uint32), t0.view(np.uint32))
     assert np.array_equal(h1, h0) and h1.mean() > 0.1
+
+
+def _check_windows(got, cfg, crops, spp, depth=0):
+    """All pixels of the windows (x0, y0, w, h) in ONE oracle call, one task per pixel."""
+    xy = np.array([(x0 + i, y0 + j) for (x0, y0, cw, ch) in crops for j in range(ch) for i in range(cw)],
+                  np.int32)
+    ref = orc.render_pixels(cfg.scene, cfg.camera, cfg.width, cfg.height, xy, spp=spp, max_depth=depth)
+    ys, xs = xy[:, 1], xy[:, 0]
+    assert np.array_equal(got["prim_id"][ys, xs], ref["prim_id"])
+    assert np.array_equal(got["t"][ys, xs].view(np.uint32), ref["t"].view(np.uint32))
+    assert_radiance(got["rgba"][ys, xs], ref["rgba"])
+    return ref
+
+
+def _silhouette_window(got, cfg, cw, ch):
+    """A cw x ch window straddling the hit / miss boundary nearest the middle of the frame."""
+    hit = got["prim_id"] >= 0
+    ys, xs = np.nonzero(hit[:, :-1] != hit[:, 1:])
+    assert len(xs) > 0
+    k = len(xs) // 2
+    return (int(min(max(xs[k] - cw // 2, 0), cfg.width - cw)),
+            int(min(max(ys[k] - ch // 2, 0), cfg.height - ch)), cw, ch)
+
+
+def test_full_size_c3_bench_shape(gpu_ctx_factory):
+    """C3 exactly as the bench renders it -- 1920x1080, 64 spp in one call = two batches of 32
+    samples (4 pixels x 32 samples per wave; queued pixels take k_primary_hard's four rounds) --
+    against the oracle on windows at the silhouette, on the mesh, the ground and the sky."""
+    cfg = scenes.c3()
+    ctx = gpu_ctx_factory(cfg.width, cfg.height)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    ctx.reset_stats()
+    ctx.set_timing(True)
+    ctx.render(cfg.spp, 0)
+    st = ctx.stats()
+    ctx.set_timing(False)
+    assert cfg.spp == 64 and st.primary_launches == 2       # two 32-sample batches through the pipeline
+    got = ctx.read_framebuffer()
+    crops = [_silhouette_window(got, cfg, 8, 4), (956, 538, 8, 4), (44, 1042, 8, 4), (904, 4, 8, 2)]
+    ref = _check_windows(got, cfg, crops, cfg.spp)
+    assert 0 < (ref["prim_id"] >= 0).sum() < len(ref["prim_id"])        # hits and misses both
+
+
+@pytest.fixture(scope="module")
+def c4_full():
+    return scenes.c4()
+
+
+@pytest.fixture(scope="module")
+def c5_full():
+    return scenes.c5()
+
+
+def test_full_size_c4_render(gpu_ctx_factory, c4_full):
+    """C4 at its full size (871 414 triangles, 3840x2160) through rt_render: k_primary /
+    k_primary_hard / k_shadow over the real tree.  (a) 2 spp against the oracle on windows at
+    the silhouette, on the mesh, the ground and the sky; (b) a 32-sample batch (the shape the
+    bench runs) equals the same 32 samples rendered one call at a time, in every bit of the
+    image, id and t buffers and in the shadow-ray count."""
+    cfg = c4_full
+    assert cfg.scene.n_tris == 871_414 and (cfg.width, cfg.height) == (3840, 2160)
+    ctx = gpu_ctx_factory(cfg.width, cfg.height)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    ctx.render(2, 0)
+    got = ctx.read_framebuffer()
+    crops = [_silhouette_window(got, cfg, 8, 4), (1916, 1078, 8, 4), (90, 2084, 8, 4), (1800, 8, 8, 2)]
+    ref = _check_windows(got, cfg, crops, 2)
+    assert 0 < (ref["prim_id"] >= 0).sum() < len(ref["prim_id"])
+    assert 0.2 < (got["prim_id"] >= 0).mean() < 1.0
+    out, shadow = [], []
+    for mode in ("batch", "one by one"):
+        ctx.reset()
+        ctx.reset_stats()
+        if mode == "batch":
+            ctx.render(32, 0)
+        else:
+            for _ in range(32):
+                ctx.render(1, 0)
+        out.append(ctx.read_framebuffer())
+        shadow.append(ctx.stats().shadow_rays)
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    assert shadow[0] == shadow[1] and shadow[0] > 0
+
+
+def test_full_size_c5_render(gpu_ctx_factory, c5_full):
+    """C5 at its full size (10 M triangles, 64 lights, 3840x2160) through rt_render: 1 spp
+    against the oracle on a handful of pixels (a hit costs the oracle 65 scans of 10 M
+    triangles), and a 16-sample batch (the bench's shape) against one call per sample."""
+    cfg = c5_full
+    assert cfg.scene.n_tris == 10_000_000 and cfg.scene.n_lights == 64
+    ctx = gpu_ctx_factory(cfg.width, cfg.height)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    ctx.render(1, 0)
+    got = ctx.read_framebuffer()
+    crops = [_silhouette_window(got, cfg, 4, 1), (1920, 1500, 4, 1), (300, 2100, 2, 1), (2000, 20, 2, 1)]
+    ref = _check_windows(got, cfg, crops, 1)
+    assert (ref["prim_id"] >= 0).sum() >= 6 and ref["shadow"] > 64
+    out, shadow = [], []
+    for mode in ("batch", "one by one"):
+        ctx.reset()
+        ctx.reset_stats()
+        if mode == "batch":
+            ctx.render(16, 0)
+        else:
+            for _ in range(16):
+                ctx.render(1, 0)
+        out.append(ctx.read_framebuffer())
+        shadow.append(ctx.stats().shadow_rays)
+    for k in ("rgba", "t", "prim_id"):
+        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
+    assert shadow[0] == shadow[1] and shadow[0] > 0

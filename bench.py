@@ -51,6 +51,7 @@ RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out pe
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
 SHADOW_RECORD_BYTES = 32.0   # k_shadow: hit record read per pixel-sample
 SHADOW_PIXEL_BYTES = 32.0    # k_shadow: fb texel read + written once per pixel per launch
+PROFILE_ROUNDS = ("r02", "r01")   # committed rocprofv3 summaries under profiles/, newest first
 
 
 def parse():
@@ -75,30 +76,33 @@ def measured_traffic(cfg_name, kernel):
     (profiles/r01_traffic.json, written by tools/pmc_traffic.py on the GPU box: FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).
     None if there is no profile for this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return float(d[cfg_name][kernel]["bytes_per_launch"])
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            return float(d[cfg_name][kernel]["bytes_per_launch"])
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 def measured_counter(cfg_name, kernel, counter):
     """Per-launch value of an SQ counter of `kernel` from the committed PMC summary
     (profiles/r01_<cfg>_pmc_sq.txt, written by tools/pmc_summary.py: one "== kernel" section
     per kernel).  None if absent."""
-    path = os.path.join(ROOT, "profiles", f"r01_{cfg_name}_pmc_sq.txt")
-    try:
-        section = None
-        for line in open(path):
-            f = line.split()
-            if f and f[0] == "==":
-                section = f[1]
-            elif f and section == kernel and f[0] == counter:
-                return float(f[f.index("launch") + 1])
-    except (OSError, ValueError, IndexError):
-        pass
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{cfg_name}_pmc_sq.txt")
+        try:
+            section = None
+            for line in open(path):
+                f = line.split()
+                if f and f[0] == "==":
+                    section = f[1]
+                elif f and section == kernel and f[0] == counter:
+                    return float(f[f.index("launch") + 1])
+        except (OSError, ValueError, IndexError):
+            pass
     return None
 
 
@@ -288,7 +292,7 @@ def main():
                 share = max(1, int(st.streams))
                 frac = valu * 4.0 / (k_ms * 1e-3 * simds * clk_hz / share)
                 insts = valu
-            out["valu_issue"] = {"insts_per_launch": insts, "source": f"profiles/r01_{cfg.name}_pmc_sq.txt",
+            out["valu_issue"] = {"insts_per_launch": insts, "source": f"profiles/r0x_{cfg.name}_pmc_sq.txt (newest round)",
                                  "simds": simds, "clock_hz": clk_hz, "frac_of_issue_slots": frac}
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (1600, 900),

@@ -677,7 +677,12 @@ def test_full_size_c5_render(gpu_ctx_factory, c5_full):
     ctx.set_camera(cfg.camera)
     ctx.render(1, 0)
     got = ctx.read_framebuffer()
-    crops = [_silhouette_window(got, cfg, 4, 1), (1920, 1500, 4, 1), (300, 2100, 2, 1), (2000, 20, 2, 1)]
+    hit = got["prim_id"] >= 0
+    ys, xs = np.nonzero(hit[:, :-4])                      # pixels on the height field, near and far
+    near, far = len(xs) // 8, (7 * len(xs)) // 8
+    miss_y, miss_x = np.nonzero(~hit[:, :-2])
+    crops = [_silhouette_window(got, cfg, 4, 1), (int(xs[near]), int(ys[near]), 4, 1),
+             (int(xs[far]), int(ys[far]), 2, 1), (int(miss_x[len(miss_x) // 2]), int(miss_y[len(miss_y) // 2]), 2, 1)]
     ref = _check_windows(got, cfg, crops, 1)
     assert (ref["prim_id"] >= 0).sum() >= 6 and ref["shadow"] > 64
     out, shadow = [], []

@@ -1,28 +1,44 @@
 #!/bin/bash
-# Round profile, run on the GPU box from the repo root:  bash tools/profile_round.sh <tag>
-# Writes gpurun_out/<tag>/: bench lines (c2, c3), rocprofv3 kernel-trace stats, and the PMC
-# passes (each its own run, as MI355X_MICROARCH.md prescribes): FETCH_SIZE, WRITE_SIZE, and
-# two SQ passes (issue / wait breakdown; scalar-cache behaviour).  tools/pmc_summary.py turns
-# them into the summaries committed under profiles/.
+# Round profile, run on the GPU box from the repo root:
+#     bash tools/profile_round.sh <tag> [config ...]        (default configs: c3 c2)
+# Writes gpurun_out/<tag>/: one bench line per config, rocprofv3 kernel-trace stats, and the PMC
+# passes (each its own run, as MI355X_MICROARCH.md prescribes): FETCH_SIZE, WRITE_SIZE, L2 hit /
+# miss, three SQ passes (issue / wait breakdown; instruction mix; lane utilisation =
+# SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)) and the scalar cache.  tools/pmc_summary.py
+# and tools/pmc_traffic.py turn them into the summaries committed under profiles/.
 set -e
 TAG=${1:-prof}
+shift || true
+CONFIGS=${@:-c3 c2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$TAG
 mkdir -p $O
-timeout -k 10 300 python bench.py --config c3 --steps 3 --warmup 1 > $O/bench_c3.json 2> $O/bench_c3.err
-timeout -k 10 300 python bench.py --config c2 --steps 5 --warmup 2 > $O/bench_c2.json 2> $O/bench_c2.err
 SQ1=SQ_WAVE_CYCLES,SQ_BUSY_CYCLES,SQ_WAIT_ANY,SQ_WAIT_INST_ANY,SQ_ACTIVE_INST_ANY,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_SCA,SQ_INSTS_VALU
 SQ2=SQ_INSTS_SALU,SQ_INSTS_SMEM,SQ_INST_CYCLES_SMEM,SQ_INSTS_LDS,SQ_WAVES,SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR,SQ_CYCLES
+SQ3=SQ_THREAD_CYCLES_VALU,SQ_ACTIVE_INST_VALU,SQ_INST_CYCLES_VALU,SQ_INSTS_VALU
 SQC=SQC_DCACHE_REQ,SQC_DCACHE_HITS,SQC_DCACHE_MISSES,SQC_DCACHE_MISSES_DUPLICATE,SQC_TC_DATA_READ_REQ,SQC_TC_STALL,SQC_DCACHE_BUSY_CYCLES
-for c in c3 c2; do
-  if [ $c = c2 ]; then A="--config c2 --steps 2 --warmup 1 --no-cpu"; else A="--config c3 --steps 1 --warmup 1 --no-cpu"; fi
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o $c -- python3 bench.py $A > $O/kt_$c.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o $c -- python3 bench.py $A > $O/fetch_$c.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o $c -- python3 bench.py $A > $O/write_$c.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc $SQ1 --output-format csv -d $O/sq1 -o $c -- python3 bench.py $A > $O/sq1_$c.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc $SQ2 --output-format csv -d $O/sq2 -o $c -- python3 bench.py $A > $O/sq2_$c.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc $SQC --output-format csv -d $O/sqc -o $c -- python3 bench.py $A > $O/sqc_$c.log 2>&1
+L2=TCC_HIT_sum,TCC_MISS_sum,TCC_REQ_sum
+for c in $CONFIGS; do
+  case $c in
+    c2) B="--config c2 --steps 5 --warmup 2";           A="--config c2 --steps 2 --warmup 1 --no-cpu";;
+    c3) B="--config c3 --steps 3 --warmup 1";           A="--config c3 --steps 1 --warmup 1 --no-cpu";;
+    c4) B="--config c4 --spp 64 --steps 2 --warmup 1";  A="--config c4 --spp 64 --steps 1 --warmup 1 --no-cpu";;
+    c5) B="--config c5 --spp 16 --steps 2 --warmup 1";  A="--config c5 --spp 16 --steps 1 --warmup 1 --no-cpu";;
+    *)  B="--config $c --steps 3 --warmup 1";           A="--config $c --steps 1 --warmup 1 --no-cpu";;
+  esac
+  echo "== $c: bench"; date +%T
+  timeout -k 10 400 python bench.py $B > $O/bench_$c.json 2> $O/bench_$c.err
+  echo "== $c: kernel trace"; date +%T
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o $c -- python3 bench.py $A > $O/kt_$c.log 2>&1
+  for pass in fetch:FETCH_SIZE write:WRITE_SIZE l2:$L2 sq1:$SQ1 sq2:$SQ2 sq3:$SQ3 sqc:$SQC; do
+    name=${pass%%:*}; ctrs=${pass#*:}
+    echo "== $c: pmc $name"; date +%T
+    timeout -s KILL 300 rocprofv3 --pmc $ctrs --output-format csv -d $O/$name -o $c -- python3 bench.py $A > $O/${name}_$c.log 2>&1
+  done
   python3 tools/pmc_traffic.py $c $O/fetch/${c}_counter_collection.csv $O/write/${c}_counter_collection.csv $O/traffic.json > $O/traffic_$c.txt
-  python3 tools/pmc_summary.py k_shadow,k_primary,k_primary_hard,k_path $O/sq1/${c}_counter_collection.csv $O/sq2/${c}_counter_collection.csv $O/sqc/${c}_counter_collection.csv > $O/sq_$c.txt
+  python3 tools/pmc_summary.py k_shadow,k_primary,k_primary_hard,k_path,k_fused $O/sq1/${c}_counter_collection.csv $O/sq2/${c}_counter_collection.csv $O/sq3/${c}_counter_collection.csv $O/sqc/${c}_counter_collection.csv $O/l2/${c}_counter_collection.csv > $O/sq_$c.txt
+  cp $O/kt/${c}_kernel_stats.csv $O/kernel_stats_$c.csv 2>/dev/null || true
+  # the raw per-dispatch CSVs are large: keep the summaries only
+  rm -rf $O/fetch/${c}_* $O/write/${c}_* $O/l2/${c}_* $O/sq1/${c}_* $O/sq2/${c}_* $O/sq3/${c}_* $O/sqc/${c}_* $O/kt/${c}_*
 done
 echo done

@@ -14,16 +14,18 @@ import numpy as np
 from .scene import CameraArgs, CameraDesc, SceneData, SceneDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB: a diagnostic build of the same library (tools/build_stamps.sh), never a fallback
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 RT_OK, RT_ERR_INVALID, RT_ERR_UNSUPPORTED, RT_ERR_DEVICE, RT_ERR_STATE, RT_ERR_IO = range(6)
 INF = np.float32(1000000.0)
+SCENE_HIT_NOALLOC_MAX_RAYS = 1 << 20     # RT_SCENE_HIT_NOALLOC_MAX_RAYS
 
 # every symbol include/rt_abi.h declares
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload_scene", "rt_set_camera", "rt_set_partition", "rt_partition_pixels", "rt_reset",
     "rt_render", "rt_read_framebuffer", "rt_local_pixel_count", "rt_local_pixel_indices",
-    "rt_export_local_rgba", "rt_scene_hit", "rt_postprocess", "rt_get_stats", "rt_reset_stats",
+    "rt_export_local_rgba", "rt_scene_hit", "rt_scene_hit_noalloc", "rt_postprocess", "rt_get_stats", "rt_reset_stats",
     "rt_set_timing", "rt_set_culling", "rt_host_bounds", "rt_last_error", "rt_obj_load", "rt_obj_free", "rt_write_ppm", "rt_write_pfm",
 ]
 
@@ -66,6 +68,7 @@ def lib():
         L.rt_local_pixel_indices.argtypes = [VP, IP]
         L.rt_export_local_rgba.argtypes = [VP, VP]
         L.rt_scene_hit.argtypes = [VP, C.c_int, FP, FP, FP, IP, IP]
+        L.rt_scene_hit_noalloc.argtypes = [VP, C.c_int, VP, VP, VP, VP, VP]
         L.rt_postprocess.argtypes = [VP, FP, FP]
         L.rt_get_stats.argtypes = [VP, C.POINTER(Stats)]
         L.rt_reset_stats.argtypes = [VP]
@@ -176,6 +179,11 @@ class Context:
         hit = np.zeros(n, np.int32)
         self._chk(lib().rt_scene_hit(self._h, n, _fp(org), _fp(dir), _fp(t), _ip(pid), _ip(hit)))
         return t, pid, hit
+
+    def scene_hit_noalloc(self, n, d_org, d_dir, d_t, d_prim_id, d_ishit):
+        """rt_scene_hit_noalloc: all five arguments are DEVICE addresses (ints) of caller-owned buffers."""
+        self._chk(lib().rt_scene_hit_noalloc(self._h, int(n), C.c_void_p(d_org), C.c_void_p(d_dir),
+                                             C.c_void_p(d_t), C.c_void_p(d_prim_id), C.c_void_p(d_ishit)))
 
     def postprocess(self, hdr=True, filtered=True):
         h, w = self.height, self.width

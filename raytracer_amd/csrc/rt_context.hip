@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,40 @@ namespace {
 constexpr uint32_t kMinLanePixels = 1u << 16;   // below this a second lane is not worth its launches
 
 thread_local std::string g_err;              // for calls that have no context yet
+
+// ---- scratch of rt_scene_hit_noalloc (the allocation-free Scene::hit, see there) ----
+// The struct-of-arrays queue of normalised rays (what rt_scene_hit allocates per call) and the
+// closest-hit kernel's chunk dispensers, in a static device array: every GPU the library runs
+// on holds its own copy, at its own address, until the process ends.  In host code `scratch`
+// is only a handle for hipGetSymbolAddress: rt_create looks the device address up once per
+// device (with that device current) and everything below uses that pointer.
+constexpr size_t kNoAllocMaxRays = RT_SCENE_HIT_NOALLOC_MAX_RAYS;
+constexpr size_t kScratchQueueBytes = kNoAllocMaxRays * 6 * sizeof(float);
+constexpr size_t kScratchCtlBytes = 256;     // two sets of kWorkSlots dispenser counters
+static_assert(2 * kWorkSlots * sizeof(uint32_t) <= kScratchCtlBytes, "dispensers do not fit");
+static __device__ __align__(256) unsigned char scratch[kScratchQueueBytes + kScratchCtlBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices];   // per device: device address of `scratch`, nullptr = not looked up yet
+
+// With `device` current: its address of `scratch` (looked up on first use).
+hipError_t scratch_address(int device, unsigned char **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices)
+        return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess)
+            return e;
+        g_scratch_ptr[device] = (unsigned char *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 } // namespace
 
@@ -92,6 +127,8 @@ struct rt_context {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;
+
+    unsigned char *scratch = nullptr;    // this device's address of the static scratch array (rt_scene_hit_noalloc)
 
     // readback staging (full image)
     float4 *img_rgba = nullptr, *img_tmp = nullptr;
@@ -406,6 +443,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_r1);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = scratch_address(device, &c->scratch);   // this device's copy, for rt_scene_hit_noalloc
     if (e != hipSuccess) {
         std::string m = std::string("rt_create: ") + hipGetErrorString(e);
         delete c;
@@ -775,6 +813,40 @@ extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float 
     free_all(tmp);
     if (rc) return rc;
     if (e != hipSuccess) return fail(c, RT_ERR_DEVICE, std::string("rt_scene_hit: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+// Scene::hit for callers that cannot allocate device memory (rt_abi.h).  The same three kernels
+// as rt_scene_hit -- normalise, closest hit, bool -- on the context's stream; the ray queue and the
+// dispensers live in this device's static scratch array, inputs and outputs are the caller's
+// device buffers.  No hipMalloc / hipFree / allocating routine on this path.
+extern "C" int rt_scene_hit_noalloc(rt_context *c, int n, const float *d_org, const float *d_dir,
+                                    float *d_t, int32_t *d_prim_id, int32_t *d_ishit)
+{
+    if (!c) return fail(nullptr, RT_ERR_INVALID, "ctx is NULL");
+    if (!c->have_scene) return fail(c, RT_ERR_STATE, "rt_scene_hit_noalloc needs rt_upload_scene first");
+    if (n < 0) return fail(c, RT_ERR_INVALID, "rt_scene_hit_noalloc: n must be >= 0");
+    if ((size_t)n > kNoAllocMaxRays)
+        return fail(c, RT_ERR_INVALID, "rt_scene_hit_noalloc: n exceeds RT_SCENE_HIT_NOALLOC_MAX_RAYS (" +
+                                           std::to_string(kNoAllocMaxRays) + " rays per call)");
+    if (n == 0) return RT_OK;
+    if (!d_org || !d_dir || !d_t || !d_prim_id || !d_ishit)
+        return fail(c, RT_ERR_INVALID, "rt_scene_hit_noalloc: device buffers must not be NULL");
+    if (!c->scratch) return fail(c, RT_ERR_STATE, "rt_scene_hit_noalloc: no scratch address for this device");
+    RT_HIP(c, hipSetDevice(c->device));
+    const uint32_t un = (uint32_t)n;
+    hipStream_t s = c->stream;
+    float *qf = (float *)c->scratch;
+    RayQueue q{qf, qf + kNoAllocMaxRays, qf + 2 * kNoAllocMaxRays, qf + 3 * kNoAllocMaxRays,
+               qf + 4 * kNoAllocMaxRays, qf + 5 * kNoAllocMaxRays};
+    uint32_t *work = (uint32_t *)(c->scratch + kScratchQueueBytes);
+    // the array keeps the last call's contents: the dispensers must start at zero
+    RT_HIP(c, hipMemsetAsync(work, 0, kScratchCtlBytes, s));
+    launch_prepare_rays(s, q, d_org, d_dir, un);
+    launch_intersect(s, c->v, q, un, d_t, d_prim_id, c->max_blocks, work, work + kWorkSlots);
+    launch_ishit(s, d_t, d_ishit, un);
+    RT_HIP(c, hipStreamSynchronize(s));
+    RT_HIP(c, hipGetLastError());
     return RT_OK;
 }
 

@@ -99,6 +99,56 @@ extern "C" void rt_debug_log(void *out, unsigned p0, unsigned n)
 }
 #endif
 
+#ifdef RT_STAMPS
+// Diagnostic build only (tools/build_stamps.sh): where a wave's cycles go.  s_memtime stamps
+// around the segments of the batch kernels, summed over all waves into g_stamps[kernel][segment]
+// (shader cycles; every stamp costs the wave a scalar-memory round trip, so totals run ~10 % high).
+//  0 wave lifetime   1 dispenser   2 unit prologue (loads until ready)   3 shading between traversals
+//  4 stash save/load 5 traverse    6 node-group load wait   7 node tests + ordering
+//  8 triangle load wait   9 triangle tests   10 unit epilogue   11 units   12 traversals
+__device__ unsigned long long g_stamps[4][16];
+extern "C" void rt_debug_stamps(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+    if (reset) {
+        unsigned long long z[64] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    }
+}
+struct Stamps {
+    unsigned long long a[13];
+    unsigned long long last;
+    __device__ __forceinline__ void start() { for (int i = 0; i < 13; i++) a[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    // close the segment that began at the previous mark and charge it to `seg`
+    __device__ __forceinline__ void mark(int seg)
+    {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        a[seg] += t - last;
+        last = t;
+    }
+    __device__ __forceinline__ void flush(int kernel)
+    {
+        if ((threadIdx.x & 63u) == 0)
+            for (int i = 0; i < 13; i++)
+                if (a[i]) atomicAdd(&g_stamps[kernel][i], a[i]);
+    }
+};
+#define RT_MARK(sp, seg) (sp).mark(seg)
+#define RT_COUNT(sp, seg) ((sp).a[seg]++)
+template <class T> __device__ __forceinline__ void stamp_arrived(const T &v)
+{
+    // the load must have landed before the stamp that follows: use its first and last dword
+    const uint32_t *w = (const uint32_t *)&v;
+    asm volatile("" :: "s"(w[0]), "s"(w[sizeof(T) / 4 - 1]));
+}
+#else
+struct Stamps { };
+#define RT_MARK(sp, seg) do { } while (0)
+#define RT_COUNT(sp, seg) do { } while (0)
+template <class T> __device__ __forceinline__ void stamp_arrived(const T &) { }
+#endif
+
 constexpr unsigned long long kHeavyFactor = 8;   // heavy = this many times the mean chunk cost (4 and 16 measured slower)
 constexpr int kSplitLevel = 2;       // cooperative chunks: subtrees of 4^(kSplitLevel+1) triangles
 
@@ -116,9 +166,12 @@ struct TravArgs {
 };
 
 __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, uint32_t node,
-                                              RayPair &r, uint32_t lanebits, int j)
+                                              RayPair &r, uint32_t lanebits, int j, Stamps &sp)
 {
+    RT_MARK(sp, 7);
     const TriRec T = load_uniform(&tris[node]);
+    stamp_arrived(T);
+    RT_MARK(sp, 8);
     bool cx = (lanebits >> (2 * j)) & 1u, cy = (lanebits >> (2 * j + 1)) & 1u;
     RT_STAT(2, 1);
     if (__ballot(cx | cy)) {
@@ -128,6 +181,7 @@ __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, u
         if (r.best.x < r.stop.x) r.bestp.x = -1.0f;
         if (r.best.y < r.stop.y) r.bestp.y = -1.0f;
     }
+    RT_MARK(sp, 9);
 }
 
 // Per-level traversal state lives in ONE VGPR: lane l holds level l's word
@@ -195,10 +249,11 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
 template <bool CULL, bool COOP, bool ORDER = true>
 __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, RayPair &r,
                                          uint32_t lane, uint32_t wib,
-                                         unsigned long long *s_best, uint32_t &cost)
+                                         unsigned long long *s_best, uint32_t &cost, Stamps &sp)
 {
     const TreeView &tv = A.tv;
     RT_STAT(0, 1);
+    RT_COUNT(sp, 12);
     unsigned long long pub0 = 0, pub1 = 0;       // what this wave last saw or wrote per ray
     if (COOP) {
         pub0 = pack_hit(r.best.x, -1);
@@ -245,7 +300,10 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                 cost++;
                 RT_STAT(1, 1);
                 if (COOP) merge_in();
+                RT_MARK(sp, 7);
                 const NodeGroup G = load_uniform(&tv.groups[lane_get(lvloff, l) + g]);
+                stamp_arrived(G);
+                RT_MARK(sp, 6);
                 uint32_t key[4], lb = 0, n_pass = 0;
 #pragma unroll
                 for (int j = 0; j < kTreeArity; j++) {
@@ -305,7 +363,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
             uint32_t node = g * kTreeArity + (uint32_t)j;
             if (l == 0) {
                 cost++;
-                test_triangle(A.tris, node, r, lanebits, j);
+                test_triangle(A.tris, node, r, lanebits, j, sp);
                 if (COOP) merge_out();
             } else {
                 l--;
@@ -315,8 +373,9 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         }
     } else {
         for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
-            test_triangle(A.tris, node, r, 0xffffffffu, 0);
+            test_triangle(A.tris, node, r, 0xffffffffu, 0, sp);
     }
+    RT_MARK(sp, 7);
     if (COOP) {
         __syncthreads();
         merge_in();                              // the block's final answer
@@ -544,7 +603,8 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         S[0].save(st);
         S[1].save(st + State::kSlots * kBlock);
         asm volatile("" ::: "memory");
-        traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost);
+        Stamps sp0;
+        traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
         asm volatile("" ::: "memory");
         S[0].load(st);
         S[1].load(st + State::kSlots * kBlock);
@@ -903,7 +963,7 @@ struct PrimaryTrace {
 template <bool CULL>
 __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv &env, uint32_t lane,
                                               uint32_t pix[2], uint32_t ctr[2], bool live[2],
-                                              PrimaryTrace &o, uint32_t &cost, uint32_t *st)
+                                              PrimaryTrace &o, uint32_t &cost, uint32_t *st, Stamps &sp)
 {
     const DevView &v = A.v;
     const uint32_t L = (uint32_t)v.n_lights;
@@ -927,7 +987,8 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
     st[2 * kBlock] = ctr[0]; st[3 * kBlock] = ctr[1];
     st[4 * kBlock] = (live[0] ? 1u : 0u) | (live[1] ? 2u : 0u);
     asm volatile("" ::: "memory");
-    traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
+    RT_MARK(sp, 3);
+    traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
     asm volatile("" ::: "memory");
     pix[0] = st[0 * kBlock]; pix[1] = st[1 * kBlock];
     ctr[0] = st[2 * kBlock]; ctr[1] = st[3 * kBlock];
@@ -988,8 +1049,10 @@ __device__ __forceinline__ void write_primary(const BatchArgs &A, const PrimaryT
 
 template <bool CULL>
 __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                             uint32_t lane, uint32_t *st)
+                                             uint32_t lane, uint32_t *st, Stamps &sp)
 {
+    RT_MARK(sp, 1);
+    RT_COUNT(sp, 11);
     const DevView &v = A.v;
     const uint32_t L = (uint32_t)v.n_lights;
     const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u, ss = 1u << A.ss_log2;
@@ -1023,7 +1086,7 @@ __device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv 
             st[(9 + h) * kBlock] = dhat[h];
         }
         PrimaryTrace o;
-        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, st);
+        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, st, sp);
         uint32_t q[2], smp[2], p[2];
         uint32_t ln = lane;
         asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
@@ -1090,10 +1153,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     const ChunkFeedback none{};
     const uint32_t px = kPathChunk >> A.ss_log2;
+    Stamps sp;
+#ifdef RT_STAMPS
+    sp.start();
+    const unsigned long long t_begin = sp.last;
+#endif
     run_chunks<CULL>(
         (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane, st); },
+        [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane, st, sp); RT_MARK(sp, 10); },
         [&](uint32_t) {});
+#ifdef RT_STAMPS
+    sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    sp.flush(0);
+#endif
 }
 
 // Candidate r of the table: level k = samples before it, of which b hits without and c hits with
@@ -1153,7 +1225,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
                 ctr[h] = e_c + 2u * a + (2u + L) * b + (3u + L) * c;
             }
             PrimaryTrace o;
-            trace_primary<CULL>(A, env, lane, pix, ctr, live, o, cost, st);
+            Stamps sp0;
+            trace_primary<CULL>(A, env, lane, pix, ctr, live, o, cost, st, sp0);
             const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
             const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
             const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
@@ -1190,8 +1263,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
 // (16 samples x 8 pixels against 1 x 128: C3 -27 % shadow time, C4 -40 %, C5 -68 %).
 template <bool CULL>
 __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                             uint32_t lane, float *st)
+                                             uint32_t lane, float *st, Stamps &sp)
 {
+    RT_MARK(sp, 1);
+    RT_COUNT(sp, 11);
     using State = RayState<true>;
     const DevView &v = A.v;
     const int L = v.n_lights;
@@ -1216,6 +1291,10 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
         }
         S[h].le = mk3(0.0f, 0.0f, 0.0f);
     }
+#ifdef RT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    RT_MARK(sp, 2);
+#endif
     RayPair w;
     const int n_lights = __ballot(hit[0] | hit[1]) ? L : 0;  // nobody hit: nothing to light
     for (int j = 0; j < n_lights; j++) {
@@ -1246,13 +1325,19 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
             continue;                                        // nobody casts towards this light
         n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
         pair_set(w, so, sd, sb, ss, cast, E);
+        RT_MARK(sp, 3);
         S[0].save(st);
         S[1].save(st + State::kSlots * kBlock);
         asm volatile("" ::: "memory");
-        traverse<CULL, false, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost);
+        RT_MARK(sp, 4);
+        traverse<CULL, false, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
         asm volatile("" ::: "memory");
         S[0].load(st);
         S[1].load(st + State::kSlots * kBlock);
+#ifdef RT_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        RT_MARK(sp, 4);
         // Scene.cu:225-241: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
         // (H3: `lightidx == idx` restated as never true for point lights)
 #pragma unroll
@@ -1274,6 +1359,7 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
                 S[h].le = add(S[h].le, S[h].contrib);
         }
     }
+    RT_MARK(sp, 3);
     v3 res[2];
 #pragma unroll
     for (int h = 0; h < 2; h++)                              // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64)
@@ -1317,6 +1403,10 @@ __device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv 
     }
     if (lane == 0 && n_shadow)
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+#ifdef RT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    RT_MARK(sp, 10);
 }
 
 template <bool CULL>
@@ -1331,10 +1421,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     const ChunkFeedback none{};
     const uint32_t px = kPathChunk >> A.ss_log2;
+    Stamps sp;
+#ifdef RT_STAMPS
+    sp.start();
+    const unsigned long long t_begin = sp.last;
+#endif
     run_chunks<CULL>(
         (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, lane, st); },
+        [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, lane, st, sp); },
         [&](uint32_t) {});
+#ifdef RT_STAMPS
+    sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    sp.flush(1);
+#endif
 }
 
 // ------------------------------------------------------------------ Scene::hit on a ray queue
@@ -1381,7 +1480,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const TravArgs T, RayQueue
         RayPair w;
         uint32_t cost = 0;
         pair_set(w, o, d, inf2, none2, live, T.tv.extent);
-        traverse<CULL, false>(T, lvloff, w, lane, 0u, nullptr, cost);
+        Stamps sp0;
+        traverse<CULL, false>(T, lvloff, w, lane, 0u, nullptr, cost, sp0);
         if (live[0]) { out_t[i[0]] = w.best.x; out_id[i[0]] = w.idx; }
         if (live[1]) { out_t[i[1]] = w.best.y; out_id[i[1]] = w.idy; }
     }

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where a wave's cycles go in the batch kernels (diagnostic build, tools/build_stamps.sh):
+
+    RT_AMD_LIB=build/stamps/librt_amd.so python tools/stamps_report.py c3 [spp]
+
+renders one warm-up and one measured step of the config at max_depth 0 and prints, per kernel,
+the share of the summed wave lifetime spent in each stamped segment."""
+import ctypes as C
+import sys
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raytracer_amd import abi, scenes  # noqa: E402
+
+SEG = ["wave lifetime", "dispenser", "unit prologue (loads)", "shading between traversals",
+       "stash save/load", "(traverse)", "node-group load wait", "node tests + ordering",
+       "triangle load wait", "triangle tests", "unit epilogue", "units", "traversals"]
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    cfg = scenes.CONFIGS[name]()
+    spp = int(sys.argv[2]) if len(sys.argv) > 2 else min(cfg.spp, 64)
+    L = abi.lib()
+    L.rt_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    with abi.Context(cfg.width, cfg.height, 0) as ctx:
+        ctx.upload_scene(cfg.scene)
+        ctx.set_camera(cfg.camera)
+        ctx.render(spp, 0)
+        ctx.reset()
+        L.rt_debug_stamps(None, 1)
+        ctx.render(spp, 0)
+        out = (C.c_uint64 * 64)()
+        L.rt_debug_stamps(out, 0)
+    for k, kname in enumerate(["k_primary", "k_shadow", "k_batch", "-"]):
+        a = [int(out[16 * k + i]) for i in range(16)]
+        if not a[0]:
+            continue
+        print(f"== {kname} ({name}, {spp} spp): {a[11]} units, {a[12]} traversals, "
+              f"{a[0] / max(a[11], 1):.0f} cycles of wave lifetime per unit")
+        for i in range(1, 11):
+            if a[i]:
+                print(f"  {SEG[i]:32s} {100.0 * a[i] / a[0]:6.2f} %   {a[i] / max(a[11], 1):10.0f} cycles / unit")
+        print(f"  {'unaccounted':32s} {100.0 * (a[0] - sum(a[1:11])) / a[0]:6.2f} %")
+
+
+if __name__ == "__main__":
+    main()

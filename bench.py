@@ -51,6 +51,9 @@ RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out pe
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
 SHADOW_RECORD_BYTES = 32.0   # k_shadow: hit record read per pixel-sample
 SHADOW_PIXEL_BYTES = 32.0    # k_shadow: fb texel read + written once per pixel per launch
+VALU_CYCLES = 2.0            # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md,
+                             # per-instruction constants; measured here too: C5's k_shadow retires one per 2.15 cycles per SIMD)
+BATCH_PIXEL_BYTES = 60.0     # k_batch, per pixel and launch: fb 16+16, rng counter 4+4, last draws 4+4, pixmap 4, id + t 8
 PROFILE_ROUNDS = ("r02", "r01")   # committed rocprofv3 summaries under profiles/, newest first
 
 
@@ -211,15 +214,20 @@ def main():
         # dominant kernel of the step: k_shadow (depth-0 pipeline over a deep tree: shadow rays
         # of a whole batch of samples) or k_path (everything of one sample).  Unit of a launch
         # = pixel-samples.
+        fused = st.batch_launches > 0
         pipeline = st.primary_launches > 0
-        kernel = "k_shadow" if pipeline else "k_path"
+        kernel = "k_batch" if fused else "k_shadow" if pipeline else "k_path"
         rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
         launches = max(1, st.path_launches)
         k_ms = st.path_ms / launches
         units_per_launch = float(st.samples) / launches
         n_pixels_rank = float(st.samples) / max(1, spp * a.steps)   # stats cover the timed steps
-        unit_bytes = (SHADOW_RECORD_BYTES + SHADOW_PIXEL_BYTES * n_pixels_rank / max(units_per_launch, 1.0)
-                      if pipeline else PIXEL_SAMPLE_BYTES)
+        if fused:      # per pixel and launch only; nothing per sample reaches memory
+            unit_bytes = BATCH_PIXEL_BYTES * (n_pixels_rank / max(1, int(st.streams))) / max(units_per_launch, 1.0)
+        elif pipeline:
+            unit_bytes = SHADOW_RECORD_BYTES + SHADOW_PIXEL_BYTES * n_pixels_rank / max(units_per_launch, 1.0)
+        else:
+            unit_bytes = PIXEL_SAMPLE_BYTES
         rays_per_launch = (float(st.shadow_rays) if pipeline else rays_k) / launches
         bytes_per_launch = (unit_bytes * units_per_launch + n_tri * TRI_REC_BYTES
                             + n_sph * SPH_BYTES)
@@ -255,6 +263,7 @@ def main():
                          "pixel_samples_per_launch": units_per_launch,
                          "rays_per_launch": rays_per_launch,
                          "concurrent_streams": 2 if pipeline else int(st.streams),
+                         "samples_per_launch_per_pixel": units_per_launch / max(1.0, n_pixels_rank / max(1, int(st.streams))) if fused else None,
                          "note": "the path is bound by VALU issue and scalar-load latency of the "
                                  "tree traversal, not by HBM (DESIGN.md); HBM fraction reported "
                                  "as asked"},
@@ -265,7 +274,7 @@ def main():
         }
         # What actually bounds the kernel: VALU issue.  Instructions per launch come from the
         # committed SQ_INSTS_VALU pass (same command, profiles/), the duration is live; a
-        # wave64 VALU instruction occupies its SIMD for 4 cycles, and the streams' launches
+        # wave64 VALU instruction occupies its SIMD for VALU_CYCLES, and the streams' launches
         # share the chip.
         if pipeline:
             out["primary_kernel"] = {"kernel": "k_primary", "launches_timed": int(st.primary_launches),
@@ -280,17 +289,21 @@ def main():
             prop = torch.cuda.get_device_properties(dev)
             simds = prop.multi_processor_count * 4
             clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-            if pipeline:
+            if fused:
+                # every stream's launches share the chip: all instructions of the step against its wall time
+                frac = valu * float(launches) / a.steps * VALU_CYCLES / (dt / a.steps * simds * clk_hz)
+                insts = valu
+            elif pipeline:
                 # k_primary and k_shadow overlap on two streams: price both kernels'
                 # instructions of one batch against the wall time of one batch
                 valu_p = ((measured_counter(cfg.name, "k_primary", "SQ_INSTS_VALU") or 0.0) +
                           (measured_counter(cfg.name, "k_primary_hard", "SQ_INSTS_VALU") or 0.0))
                 batch_s = dt / max(1.0, float(launches))
-                frac = (valu + valu_p) * 4.0 / (batch_s * simds * clk_hz)
+                frac = (valu + valu_p) * VALU_CYCLES / (batch_s * simds * clk_hz)
                 insts = valu + valu_p
             else:
                 share = max(1, int(st.streams))
-                frac = valu * 4.0 / (k_ms * 1e-3 * simds * clk_hz / share)
+                frac = valu * VALU_CYCLES / (k_ms * 1e-3 * simds * clk_hz / share)
                 insts = valu
             out["valu_issue"] = {"insts_per_launch": insts, "source": f"profiles/r0x_{cfg.name}_pmc_sq.txt (newest round)",
                                  "simds": simds, "clock_hz": clk_hz, "frac_of_issue_slots": frac}

@@ -93,6 +93,8 @@ typedef struct rt_stats {
     double primary_ms;       /* their summed HIP-event duration                       */
     uint64_t coop_chunks;    /* k_path chunks run in the cooperative form (four waves sharing the
                                 traversals of one chunk; max_depth > 0 over a deep tree)        */
+    uint64_t batch_launches; /* launches of k_batch (max_depth 0 over a deep tree: one per batch of
+                                samples and stream); they are the path_launches then           */
 } rt_stats;
 
 /* Replaces the surface/graph set-up of initCUDA (kernel.cu:193-256): creates the

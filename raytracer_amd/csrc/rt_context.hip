@@ -115,6 +115,8 @@ struct rt_context {
     SampleBatch batch[2]{};
     uint32_t batch_cap = 0;              // samples per record buffer
     int batch_wanted = 64;
+    bool fused = true;                   // depth 0 over a deep tree: one k_batch per batch (RT_FUSED=0: the three-kernel pipeline)
+    uint64_t batch_launches = 0;         // launches of k_batch
     uint64_t primary_launches = 0;
     double primary_ms = 0.0;
     std::vector<hipEvent_t> ev_pool2;    // (start, stop) pairs around k_primary launches
@@ -473,6 +475,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
         if (!ok) rc = fail(c, RT_ERR_DEVICE, "rt_create: could not create pipeline streams");
     }
     if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_FUSED")) c->fused = std::atoi(e) != 0;
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -619,7 +622,41 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
     hipStream_t s0 = c->stream;
-    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3) {
+    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3 && c->fused) {
+        // Depth 0 over a deep tree, one kernel per batch of samples and lane (k_batch,
+        // rt_kernels.hip): camera rays from predicted counters, shadow rays and the running mean
+        // of a unit without leaving the wave.  The lanes' launches follow each other on their own
+        // streams, so one lane's tail is filled by the other's next launch.
+        const int want = n_samples >= 64 ? 32 : 16;
+        const uint32_t cap = (uint32_t)std::min(std::max(n_samples, 1), std::min(c->batch_wanted, want));
+        RT_HIP(c, hipEventRecord(c->ev_r0, s0));
+        for (int k = 0; k < c->n_lanes; k++)
+            RT_HIP(c, hipStreamWaitEvent(c->lanes[k].stream, c->ev_r0, 0));
+        for (int done = 0; done < n_samples;) {
+            const uint32_t S = (uint32_t)std::min<int>((int)cap, n_samples - done);
+            for (int k = 0; k < c->n_lanes; k++) {
+                Lane &ln = c->lanes[k];
+                if (ln.hi <= ln.lo) continue;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (c->timing) { e0 = next_event(c); e1 = next_event(c); }
+                if (e0) (void)hipEventRecord(e0, ln.stream);
+                launch_batch(ln.stream, c->v, ln.lo, ln.hi - ln.lo, S, c->cnt, c->max_blocks, ln.ctl,
+                             ln.ctl->work[ln.seq & 1u], ln.ctl->work[(ln.seq + 1u) & 1u]);
+                ln.seq++;
+                if (e1) (void)hipEventRecord(e1, ln.stream);
+                c->launches++;
+                c->batch_launches++;
+            }
+            c->cnt += (int)S;
+            done += (int)S;
+            c->samples += (uint64_t)c->n_local * S;
+            c->primary += (uint64_t)c->n_local * S;
+        }
+        for (int k = 0; k < c->n_lanes; k++) {
+            RT_HIP(c, hipEventRecord(c->lanes[k].done, c->lanes[k].stream));
+            RT_HIP(c, hipStreamWaitEvent(s0, c->lanes[k].done, 0));
+        }
+    } else if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3) {
         // Depth 0 over a deep tree (a shallow one has no costly chunks to wait for, and the
         // single path kernel moves fewer bytes): primary hits of a batch of samples on one stream, their shadow rays and
         // the accumulation on a second one, a batch behind (rt_kernels.hip, "depth 0 in
@@ -901,6 +938,7 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->primary_launches = c->primary_launches;
     st->primary_ms = c->primary_ms;
     st->coop_chunks = coop_total;
+    st->batch_launches = c->batch_launches;
     return RT_OK;
 }
 
@@ -918,6 +956,7 @@ extern "C" int rt_reset_stats(rt_context *c)
     RT_HIP(c, hipMemset(c->shade_ctl, 0, sizeof(Ctl)));
     c->shade_seq = 0;
     c->primary_launches = 0;
+    c->batch_launches = 0;
     c->primary_ms = 0.0;
     c->samples = c->primary = c->launches = c->timed_launches = 0;
     c->path_ms = c->render_ms = 0.0;

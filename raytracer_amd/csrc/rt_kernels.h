@@ -116,6 +116,11 @@ void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_sampl
                    const SampleBatch &b, int cnt0, int max_blocks, Ctl *ctl, uint32_t *work,
                    uint32_t *work_next);
 
+// The same in ONE kernel per batch, over local pixels [p0, p0 + n): camera rays, the pixels the
+// prediction fails on, shadow rays and the running mean without leaving the wave (k_batch).
+void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
+                  int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next);
+
 // Scene::hit on a queue of caller rays (rt_scene_hit).
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,
                       float *out_t, int32_t *out_id, int max_blocks, uint32_t *work,

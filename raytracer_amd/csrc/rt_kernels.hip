@@ -909,7 +909,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
 struct BatchArgs {
     DevView v;
     TravArgs T;
-    uint32_t n;                      // pixels of the partition
+    uint32_t p0, n;                  // local pixels [p0, p0 + n) (k_primary / k_shadow: p0 = 0, the partition)
     uint32_t n_samples;              // samples in this batch
     SampleBatch b;
     uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2): fixes the record layout
@@ -1436,6 +1436,436 @@ __global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_
 #endif
 }
 
+// ------------------------------------------------------------------ depth 0, one kernel per batch
+// k_batch does for a unit (px pixels x ss samples = 128 rays of one wave) everything the three
+// kernels above do, without leaving the wave: camera rays from predicted counters (two rounds),
+// the pixels the prediction fails on by enumeration (the wave itself, one pixel at a time), then
+// lights, shadow rays and the pixels' running mean.  The hit records never reach memory: they
+// sit in LDS (8 dwords per ray, row-major by field, one column per lane) from the moment a
+// sample's camera ray is final until its shadow rays are done; a record traced by ANOTHER lane
+// (the enumeration walks one pixel's candidates on all lanes) is written straight into the
+// column of the lane that owns the sample.  What the wave waits for besides arithmetic is taken
+// off its critical path: the next unit's ticket is drawn from the dispenser while this unit is
+// traced, the framebuffer texels are requested before the shadow rays and used after them, and
+// the running mean reads the samples' radiance from LDS (one owner lane per pixel, in sample
+// order: kernel.cu:65-66,75,77).
+constexpr int kRecRows = 8;                  // pos (3), normal (3), dot(-dir, normal), model
+constexpr int kFuseTmpRows = 14;             // phase P: trace_primary's 5 + 8 of the unit; phase S: 7 per ray
+constexpr int kFuseRows = 2 * kRecRows + kFuseTmpRows;
+static_assert(kFuseTmpRows >= kPrimSlots + 1, "phase P rows");
+
+// Record of slot r (lane r & 63, half r >> 6) of this wave; col0 = column of the wave's lane 0.
+__device__ __forceinline__ void put_record(uint32_t *col0, uint32_t r, const PrimaryTrace &o, int h)
+{
+    uint32_t *c = col0 + (r & 63u) + (r >> 6) * (uint32_t)(kRecRows * kBlock);
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        c[k * kBlock] = __float_as_uint(o.rec[h][k]);
+    c[7 * kBlock] = (uint32_t)o.model[h];
+}
+// What the last sample of a batch leaves behind per pixel: id / t buffers, the stream's counter
+// and the draws it consumed (what the next batch predicts from).
+__device__ __forceinline__ void write_last(const BatchArgs &A, const PrimaryTrace &o, int h,
+                                           uint32_t p, uint32_t ctr)
+{
+    A.v.first_id[p] = o.id[h];
+    A.v.first_t[p] = o.t[h];
+    A.v.rng_ctr[p] = ctr + o.delta[h];
+    A.v.last_draws[p] = o.delta[h];
+}
+
+template <bool CULL>
+__device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
+                                           uint32_t lane, uint32_t *col, uint32_t *next_counter,
+                                           uint32_t &ticket, Stamps &sp)
+{
+    const DevView &v = A.v;
+    const uint32_t L = (uint32_t)v.n_lights;
+    const float E = A.T.tv.extent;
+    const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u, ss = 1u << A.ss_log2;
+    const uint32_t p_end = A.p0 + A.n;
+    uint32_t *const col0 = col - lane;                      // column of this wave's lane 0
+    uint32_t *const tmp = col + 2 * kRecRows * kBlock;       // this lane's phase rows
+    uint32_t *const tmp0 = col0 + 2 * kRecRows * kBlock;
+    uint32_t cost = 0;
+    RT_MARK(sp, 1);
+    RT_COUNT(sp, 11);
+
+    // ---------------- phase P: the camera rays' closest hits (primary_unit, records to LDS)
+    uint32_t pix[2], base_c[2], base_s[2], dhat[2];
+    bool todo[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t r = (uint32_t)h * 64u + lane;
+        const uint32_t pl = A.p0 + (unit << px_log2) + (r & px_mask);
+        todo[h] = pl < p_end && (r >> px_log2) < A.n_samples;
+        const uint32_t p = min(pl, p_end - 1u);
+        pix[h] = v.pixmap[p];
+        base_c[h] = v.rng_ctr[p];
+        base_s[h] = 0u;
+        const uint32_t last = v.last_draws[p];
+        dhat[h] = last ? last : 3u + L;
+        col[(h * kRecRows + 7) * kBlock] = 0xffffffffu;     // no record yet: model = -1
+    }
+    // the NEXT unit's ticket: drawn behind the prologue's loads, it comes back while this unit is traced
+    if (lane == 0)
+        ticket = atomicAdd(next_counter, 1u);
+    for (int round = 0; round < 2; round++) {
+        if (!__ballot(todo[0] | todo[1]))
+            break;
+        uint32_t ctr[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t smp = ((uint32_t)h * 64u + lane) >> px_log2;
+            ctr[h] = base_c[h] + (smp - base_s[h]) * dhat[h];
+            tmp[(5 + h) * kBlock] = base_c[h];
+            tmp[(7 + h) * kBlock] = base_s[h];
+            tmp[(9 + h) * kBlock] = dhat[h];
+        }
+        PrimaryTrace o;
+        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, tmp, sp);
+        uint32_t q[2], smp[2], p[2];
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t r = (uint32_t)h * 64u + ln;
+            q[h] = r & px_mask;
+            smp[h] = r >> px_log2;
+            p[h] = min(A.p0 + (unit << px_log2) + q[h], p_end - 1u);
+            base_c[h] = tmp[(5 + h) * kBlock];
+            base_s[h] = tmp[(7 + h) * kBlock];
+            dhat[h] = tmp[(9 + h) * kBlock];
+        }
+        const unsigned long long m0 = __ballot(todo[0] && o.delta[0] != dhat[0]);
+        const unsigned long long m1 = __ballot(todo[1] && o.delta[1] != dhat[1]);
+        uint32_t first[2], src[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            first[h] = ss;
+            for (uint32_t k = ss; k-- > 0u;) {
+                const uint32_t r = (k << px_log2) + q[h];
+                const bool bit = (((r < 64u ? m0 : m1) >> (r & 63u)) & 1ull) != 0ull;
+                first[h] = bit ? k : first[h];
+            }
+            src[h] = (min(first[h], ss - 1u) << px_log2) + q[h];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t lo = (uint32_t)__shfl((int)o.delta[0], (int)(src[h] & 63u));
+            const uint32_t hi = (uint32_t)__shfl((int)o.delta[1], (int)(src[h] & 63u));
+            const uint32_t dj = src[h] < 64u ? lo : hi;
+            if (todo[h] && smp[h] <= first[h]) {             // traced from the right counter: final
+                put_record(col0, (uint32_t)h * 64u + ln, o, h);
+                if (smp[h] + 1u == A.n_samples)
+                    write_last(A, o, h, p[h], ctr[h]);
+                todo[h] = false;
+            }
+            if (first[h] < ss) {                             // the pixel goes on from behind sample `first`
+                const bool changed = first[h] == base_s[h];
+                base_c[h] += (first[h] - base_s[h]) * dhat[h] + dj;
+                base_s[h] = first[h] + 1u;
+                dhat[h] = changed ? dj : dhat[h];
+            }
+        }
+    }
+
+    // ---------------- phase H: pixels still open after two rounds (k_primary_hard, on this wave)
+    {
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));
+        unsigned long long open[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t r = (uint32_t)h * 64u + ln;
+            open[h] = __ballot(todo[h] && (r >> px_log2) == base_s[h]);
+            tmp[(5 + h) * kBlock] = base_c[h];               // read back below from the speaking lane's column
+            tmp[(7 + h) * kBlock] = base_s[h];
+        }
+        while (open[0] | open[1]) {
+            const int hh = open[0] ? 0 : 1;
+            const uint32_t sl = (uint32_t)__builtin_ctzll(open[hh]);
+            open[hh] &= open[hh] - 1ull;
+            const uint32_t qq = ((uint32_t)hh * 64u + sl) & px_mask;
+            const uint32_t p1 = min(A.p0 + (unit << px_log2) + qq, p_end - 1u);
+            uint32_t e_c = tmp0[sl + (5 + hh) * kBlock];     // wave-uniform LDS reads
+            uint32_t e_s = tmp0[sl + (7 + hh) * kBlock];
+            e_c = (uint32_t)__builtin_amdgcn_readfirstlane(e_c);
+            e_s = (uint32_t)__builtin_amdgcn_readfirstlane(e_s);
+            const uint32_t pix1 = v.pixmap[p1];
+            for (int round = 0; round < 16 && e_s < A.n_samples; round++) {
+                const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);
+                uint32_t hpix[2] = {pix1, pix1}, ctr[2];
+                bool live[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint32_t k, a, b, c;
+                    hard_candidate((uint32_t)h * 64u + lane, k, a, b, c);
+                    live[h] = k < e_n;
+                    ctr[h] = e_c + 2u * a + (2u + L) * b + (3u + L) * c;
+                }
+                // the unit's open-pixel bookkeeping sits in rows 5-8 of every lane's column and
+                // must survive this traversal: trace_primary parks only in rows 0-4
+                PrimaryTrace o;
+                trace_primary<CULL>(A, env, lane, hpix, ctr, live, o, cost, tmp, sp);
+                const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
+                const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
+                const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
+                const unsigned long long b1 = __ballot(live[1] && o.delta[1] == 2u + L);
+                unsigned long long c0 = 0ull, c1 = 0ull;     // walk the chain through the table (wave-uniform)
+                uint32_t b = 0, c = 0, c_new = e_c;
+                for (uint32_t k = 0; k < e_n; k++) {
+                    const uint32_t t = b + c;
+                    const uint32_t r = hard_level_off(k) + t * (t + 1u) / 2u + c;
+                    const unsigned long long bit = 1ull << (r & 63u);
+                    if (r < 64u) c0 |= bit; else c1 |= bit;
+                    if (((r < 64u ? u0 : u1) & bit) != 0ull)      { c_new += 3u + L; c++; }
+                    else if (((r < 64u ? b0 : b1) & bit) != 0ull) { c_new += 2u + L; b++; }
+                    else                                          { c_new += 2u; }
+                }
+                uint32_t l2 = lane;
+                asm volatile("" : "+v"(l2));
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if ((((h ? c1 : c0) >> l2) & 1ull) != 0ull) {
+                        uint32_t k, ca, cb, cc;
+                        hard_candidate((uint32_t)h * 64u + l2, k, ca, cb, cc);
+                        const uint32_t s = e_s + k;
+                        put_record(col0, (s << px_log2) + qq, o, h);
+                        if (s + 1u == A.n_samples)
+                            write_last(A, o, h, p1, ctr[h]);
+                    }
+                e_s += e_n;
+                e_c = c_new;
+            }
+        }
+    }
+    // every record of the unit is final and in LDS; lanes read their own column from here on
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---------------- phase S: lights, shadow rays, the pixels' running mean (shadow_chunk)
+    uint32_t ln = lane;
+    asm volatile("" : "+v"(ln));
+    const uint32_t own_pl = A.p0 + (unit << px_log2) + ln;
+    const bool owner = ln <= px_mask && own_pl < p_end;     // px == 128: both halves, below
+    // the framebuffer texels: requested now, used after the shadow rays
+    float4 prev0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), prev1 = prev0;
+    if (px_log2 == 7u) {
+        if (own_pl < p_end) prev0 = v.fb[own_pl];
+        if (own_pl + 64u < p_end) prev1 = v.fb[own_pl + 64u];
+    } else if (owner) {
+        prev0 = v.fb[own_pl];
+    }
+    struct RS { v3 pos, normal; float wo_y; int model; v3 le, contrib; float thr; } S[2];
+    bool hit[2], cast[2] = {false, false};
+    auto load_rec = [&](int h) {
+        const uint32_t *c = col + h * kRecRows * kBlock;
+        S[h].pos = mk3(__uint_as_float(c[0]), __uint_as_float(c[kBlock]), __uint_as_float(c[2 * kBlock]));
+        S[h].normal = mk3(__uint_as_float(c[3 * kBlock]), __uint_as_float(c[4 * kBlock]), __uint_as_float(c[5 * kBlock]));
+        S[h].wo_y = __uint_as_float(c[6 * kBlock]);
+        S[h].model = (int)c[7 * kBlock];
+    };
+    auto as_hit = [&](int h) {
+        Hit H;
+        H.pos = S[h].pos; H.normal = S[h].normal;
+        H.tangent = mk3(0.0f, 0.0f, 0.0f);
+        H.color = mk3(-1.0f, -1.0f, -1.0f);                  // H5: unbound mesh texture / quadrics leave rec.color
+        H.model = S[h].model;
+        return H;
+    };
+    uint32_t n_shadow = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        load_rec(h);
+        hit[h] = S[h].model >= 0;
+        S[h].le = mk3(0.0f, 0.0f, 0.0f);
+        S[h].contrib = mk3(0.0f, 0.0f, 0.0f);
+        S[h].thr = 0.0f;
+    }
+    RT_MARK(sp, 2);
+    RayPair w;
+    const uint32_t n_lights = __ballot(hit[0] | hit[1]) ? L : 0u;   // nobody hit: nothing to light
+    for (uint32_t j = 0; j < n_lights; j++) {
+        // one delta light against the hits: Scene.cu:83-120 -> evaluateDirectLight :205-224
+        const LightRec light = load_uniform(&v.lights[j]);
+        v3 so[2], sd[2];
+        float sb[2], st2[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            cast[h] = false;
+            so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+            sb[h] = kInf; st2[h] = -1.0f;
+            if (hit[h]) {
+                LightSample ls = sample_point_light(as_hit(h), v.models[S[h].model], S[h].wo_y, light);
+                cast[h] = ls.cast;
+                so[h] = ls.sr.o; sd[h] = ls.sr.d;
+                S[h].thr = fmaxf(ls.thr, 0.0f);              // Scene.cu:227 rhs
+                S[h].contrib = ls.contrib;
+                if (A.occlusion) {
+                    float m = 1e-4f * (fabsf(S[h].thr) + fabsf(so[h].x) + fabsf(so[h].y) + fabsf(so[h].z)) + 1e-6f;
+                    sb[h] = fminf(kInf, S[h].thr + m);
+                    st2[h] = S[h].thr - m;
+                }
+            }
+        }
+        const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+        if (!(c0 | c1))
+            continue;                                        // nobody casts towards this light
+        n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+        pair_set(w, so, sd, sb, st2, cast, E);
+        RT_MARK(sp, 3);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                        // the record itself stays where it is
+            float *t7 = (float *)tmp + h * 7 * kBlock;
+            t7[0] = S[h].le.x; t7[kBlock] = S[h].le.y; t7[2 * kBlock] = S[h].le.z;
+            t7[3 * kBlock] = S[h].contrib.x; t7[4 * kBlock] = S[h].contrib.y; t7[5 * kBlock] = S[h].contrib.z;
+            t7[6 * kBlock] = S[h].thr;
+        }
+        asm volatile("" ::: "memory");
+        RT_MARK(sp, 4);
+        traverse<CULL, false, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float *t7 = (const float *)tmp + h * 7 * kBlock;
+            S[h].le = mk3(t7[0], t7[kBlock], t7[2 * kBlock]);
+            S[h].contrib = mk3(t7[3 * kBlock], t7[4 * kBlock], t7[5 * kBlock]);
+            S[h].thr = t7[6 * kBlock];
+            load_rec(h);
+            hit[h] = S[h].model >= 0;
+        }
+        RT_MARK(sp, 4);
+        // Scene.cu:225-241: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
+        // (H3: `lightidx == idx` restated as never true for delta lights)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool did = h ? (((c1 >> lane) & 1ull) != 0ull) : (((c0 >> lane) & 1ull) != 0ull);
+            if (!did)
+                continue;
+            const float best = h ? w.best.y : w.best.x;
+            const int32_t sid = h ? w.idy : w.idx;
+            bool blocked = false;
+            if (scene_ishit(best) && sid >= 0) {
+                Ray sr;
+                sr.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+                sr.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+                v3 hp = sid < v.n_tris ? ray_pos(sr, best)
+                                       : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
+                blocked = length(sub(hp, sr.o)) < S[h].thr;
+            }
+            if (!blocked)                                    // res += ... in light order (Scene.cu:120)
+                S[h].le = add(S[h].le, S[h].contrib);
+        }
+    }
+    RT_MARK(sp, 3);
+    // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64).  The radiance of every
+    // sample goes to LDS with the sample's weights 1 / cnt and (1 / cnt)(cnt - 1) (kernel.cu:65-66).
+    float *const ft = (float *)tmp;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const v3 res = hit[h] ? add(mk3(0.0f, 0.0f, 0.0f), mul(mk3(1.0f, 1.0f, 1.0f), S[h].le)) : mk3(0.0f, 0.0f, 0.0f);
+        const uint32_t smp = ((uint32_t)h * 64u + ln) >> px_log2;
+        const int cnt = A.cnt0 + (int)smp + 1;
+        const float frac1 = 1.0f / cnt, frac2 = frac1 * (cnt - 1);
+        ft[(5 * h + 0) * kBlock] = res.x; ft[(5 * h + 1) * kBlock] = res.y; ft[(5 * h + 2) * kBlock] = res.z;
+        ft[(5 * h + 3) * kBlock] = frac1; ft[(5 * h + 4) * kBlock] = frac2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    if (px_log2 == 7u) {                                     // one sample: both pixels of a lane, no exchange
+        if (A.n_samples) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t pl = own_pl + (uint32_t)h * 64u;
+                if (pl < p_end) {
+                    float4 prev = h ? prev1 : prev0;
+                    const float frac1 = ft[(5 * h + 3) * kBlock], frac2 = ft[(5 * h + 4) * kBlock];
+                    prev.x = frac2 * prev.x + frac1 * ft[(5 * h + 0) * kBlock];
+                    prev.y = frac2 * prev.y + frac1 * ft[(5 * h + 1) * kBlock];
+                    prev.z = frac2 * prev.z + frac1 * ft[(5 * h + 2) * kBlock];
+                    prev.w = 1.0f;
+                    v.fb[pl] = prev;
+                }
+            }
+        }
+    } else if (owner) {
+        // lane q < px owns pixel q: its samples in order, each from the column of the lane that traced it
+        const float *const f0 = (const float *)tmp0;
+        float4 prev = prev0;
+        for (uint32_t smp = 0; smp < A.n_samples; smp++) {
+            const uint32_t r = (smp << px_log2) + ln;
+            const float *c = f0 + (r & 63u) + (r >> 6) * (5u * kBlock);
+            const float frac1 = c[3 * kBlock], frac2 = c[4 * kBlock];
+            prev.x = frac2 * prev.x + frac1 * c[0];
+            prev.y = frac2 * prev.y + frac1 * c[kBlock];
+            prev.z = frac2 * prev.z + frac1 * c[2 * kBlock];
+            prev.w = 1.0f;
+        }
+        v.fb[own_pl] = prev;
+    }
+    if (lane == 0 && n_shadow)
+        atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+    // the next unit's phase P writes these rows: every lane's reads above must be done first
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    RT_MARK(sp, 10);
+}
+
+// One kernel per batch and pixel range.  The grid is what is resident at once; waves draw units
+// from one dispenser per XCD (run_chunks' phase 2: every XCD first works through its own eighth
+// of the range -- a band of the image, hence a part of the tree its L2 can hold -- then helps with
+// the others'), one ticket ahead.
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 4) void k_batch(const BatchArgs A, uint32_t *__restrict__ work,
+                                                     uint32_t *__restrict__ work_next)
+{
+    __shared__ uint32_t s_lds[kFuseRows][kBlock];
+    uint32_t *col = &s_lds[0][threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    env.feedback = false; env.heavy_cost = 0xffffffffu; env.mean_cost = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
+        work_next[threadIdx.x] = 0u;                         // the next launch's dispensers (stream-ordered after us)
+    Stamps sp;
+#ifdef RT_STAMPS
+    sp.start();
+    const unsigned long long t_begin = sp.last;
+#endif
+    const uint32_t px = kPathChunk >> A.ss_log2;
+    const uint32_t n_units = (A.n + px - 1u) / px;
+    const uint32_t per = (n_units + 7u) / 8u, xcd = blockIdx.x & 7u;
+    uint32_t stage = 0, y = xcd, base = y * per;
+    uint32_t size = base < n_units ? min(per, n_units - base) : 0u;
+    uint32_t ticket = 0;
+    if (lane == 0)
+        ticket = atomicAdd(&work[y], 1u);
+    for (;;) {
+        uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
+        while (d >= size) {                                  // this band is used up: on to the next XCD's
+            if (++stage >= 8u)
+                break;
+            y = (xcd + stage) & 7u;
+            base = y * per;
+            size = base < n_units ? min(per, n_units - base) : 0u;
+            d = size;
+            if (size) {
+                if (lane == 0)
+                    ticket = atomicAdd(&work[y], 1u);
+                d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
+            }
+        }
+        if (stage >= 8u)
+            break;
+        fused_unit<CULL>(A, env, base + d, lane, col, &work[y], ticket, sp);
+    }
+#ifdef RT_STAMPS
+    sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    sp.flush(2);
+#endif
+}
+
 // ------------------------------------------------------------------ Scene::hit on a ray queue
 template <bool CULL>
 __global__ __launch_bounds__(kBlock) void k_intersect(const TravArgs T, RayQueue q, uint32_t count,
@@ -1696,6 +2126,21 @@ void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_sampl
     const unsigned long long units = (n + px - 1) / px;
     const uint32_t g = batch_grid((uint32_t)units, (uint32_t)std::max(max_blocks, 1) * 4u);
     k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+}
+
+void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
+                  int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next)
+{
+    if (n == 0 || n_samples == 0)
+        return;
+    SampleBatch none{};
+    BatchArgs A = batch_args(v, n, n_samples, none, ctl);
+    A.p0 = p0;
+    A.cnt0 = cnt0;
+    const uint32_t px = kPathChunk >> A.ss_log2;
+    const uint32_t units = (n + px - 1) / px;
+    const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * 4u);
+    k_batch<true><<<g, kBlock, 0, s>>>(A, work, work_next);   // the batch kernels run with culling only (rt_render)
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

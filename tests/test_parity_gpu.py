@@ -311,7 +311,7 @@ def test_sample_batches_with_spheres_and_ties(gpu_ctx_factory):
         stats.append(ctx.stats())
     ctx.set_culling(1)
     ctx.set_timing(False)
-    assert stats[0].primary_launches > 0 and stats[1].primary_launches == 0   # batch kernels vs path kernel
+    assert stats[0].batch_launches > 0 and stats[1].batch_launches == 0       # batch kernel vs path kernel
     for k in ("rgba", "t", "prim_id"):
         assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
     ref = orc.render(scene, cam, 96, 64, spp=18, max_depth=0)
@@ -605,7 +605,7 @@ def _silhouette_window(got, cfg, cw, ch):
 
 def test_full_size_c3_bench_shape(gpu_ctx_factory):
     """C3 exactly as the bench renders it -- 1920x1080, 64 spp in one call = two batches of 32
-    samples (4 pixels x 32 samples per wave; queued pixels take k_primary_hard's four rounds) --
+    samples (4 pixels x 32 samples per wave; open pixels take the enumeration's four rounds) --
     against the oracle on windows at the silhouette, on the mesh, the ground and the sky."""
     cfg = scenes.c3()
     ctx = gpu_ctx_factory(cfg.width, cfg.height)
@@ -616,7 +616,7 @@ def test_full_size_c3_bench_shape(gpu_ctx_factory):
     ctx.render(cfg.spp, 0)
     st = ctx.stats()
     ctx.set_timing(False)
-    assert cfg.spp == 64 and st.primary_launches == 2       # two 32-sample batches through the pipeline
+    assert cfg.spp == 64 and st.batch_launches == 2 * st.streams   # two 32-sample batches per stream through k_batch
     got = ctx.read_framebuffer()
     crops = [_silhouette_window(got, cfg, 8, 4), (956, 538, 8, 4), (44, 1042, 8, 4), (904, 4, 8, 2)]
     ref = _check_windows(got, cfg, crops, cfg.spp)

@@ -16,20 +16,20 @@ triangles, 3 lights with shadow rays, 64 spp).  `--config c2` runs configs[1] (C
 box, 36 triangles, 16 spp), whose whole step is a few milliseconds.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: over a deep tree
-k_shadow (lights and shadow rays of a whole batch of samples; the camera rays' closest
-hits come from k_primary a batch ahead, `primary_kernel` in the line), over a shallow
-one k_path (the whole path of a pixel-sample in one launch).  Algorithmic bytes per
-launch / its mean HIP-event duration (events on the stream the kernel runs on), against
-the 8 TB/s HBM peak.  Unit = one pixel-sample.  Algorithmic bytes per unit (DESIGN.md,
-"Measurement"): k_shadow 32-byte hit record read + the framebuffer texel read and written
-once per batch (32 B / samples of the batch, it keeps the running mean itself); k_path 52 B = framebuffer texel read + write (32), RNG counter read + write (8),
-pixel-map entry (4), id + t buffers (8); plus one pass over the scene records per launch
-(64 B triangle record + 32 B of box tree per triangle, 132 B per sphere).  The figure
-SURVEY 8(d) defined for a plain scan (every ray streams every triangle, one fetch shared
-by 256 rays) is reported next to it as `scan_equivalent`: it is what a scan would have
-had to move to produce the same result in the same time.  `cpu_baseline` is the CPU
-oracle (a port of the reference's per-pixel code) timed on this box's host cores on a
-bounded crop of the same workload.
+k_batch (camera rays, shadow rays and running mean of a whole batch of samples, one launch
+per batch and stream), over a shallow one k_path (the whole path of a pixel-sample in one
+launch).  Algorithmic bytes per launch / its mean HIP-event duration (events on the stream
+the kernel runs on), against the 8 TB/s HBM peak.  Unit = one pixel-sample.  Algorithmic
+bytes per unit ("Measurement"): k_batch moves nothing per sample -- per pixel and
+launch the framebuffer texel (read + write), the RNG counter and draw count (read + write),
+the pixel-map entry and the id / t buffers, 60 B; k_path 52 B per pixel-sample = framebuffer
+texel read + write (32), RNG counter read + write (8), pixel-map entry (4), id + t buffers
+(8); plus one pass over the scene records per launch (64 B triangle record + 32 B of box
+tree per triangle, 132 B per sphere).  The figure SURVEY 8(d) defined for a plain scan (every
+ray streams every triangle, one fetch shared by 256 rays) is reported next to it as
+`scan_equivalent`: it is what a scan would have had to move to produce the same result in
+the same time.  `cpu_baseline` is the CPU oracle (a port of the reference's per-pixel code)
+timed on this box's host cores on a bounded crop of the same workload.
 """
 import argparse
 import ctypes as C
@@ -49,10 +49,8 @@ SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
 RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out per ray
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
-SHADOW_RECORD_BYTES = 32.0   # k_shadow: hit record read per pixel-sample
-SHADOW_PIXEL_BYTES = 32.0    # k_shadow: fb texel read + written once per pixel per launch
 VALU_CYCLES = 2.0            # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md,
-                             # per-instruction constants; measured here too: C5's k_shadow retires one per 2.15 cycles per SIMD)
+                             # per-instruction constants; measured here too: C5's shadow rays retire one per 2.15 cycles per SIMD, profiles/r02_c5_*)
 BATCH_PIXEL_BYTES = 60.0     # k_batch, per pixel and launch: fb 16+16, rng counter 4+4, last draws 4+4, pixmap 4, id + t 8
 PROFILE_ROUNDS = ("r02", "r01")   # committed rocprofv3 summaries under profiles/, newest first
 
@@ -211,12 +209,10 @@ def main():
     if rank == 0:
         sc = cfg.scene
         n_tri, n_sph = sc.n_tris, sc.n_quads
-        # dominant kernel of the step: k_shadow (depth-0 pipeline over a deep tree: shadow rays
-        # of a whole batch of samples) or k_path (everything of one sample).  Unit of a launch
-        # = pixel-samples.
+        # dominant kernel of the step: k_batch (depth 0 over a deep tree: a whole batch of samples)
+        # or k_path (everything of one sample).  Unit of a launch = pixel-samples.
         fused = st.batch_launches > 0
-        pipeline = st.primary_launches > 0
-        kernel = "k_batch" if fused else "k_shadow" if pipeline else "k_path"
+        kernel = "k_batch" if fused else "k_path"
         rays_k = float(st.primary_rays + st.shadow_rays + st.bounce_rays)   # this rank
         launches = max(1, st.path_launches)
         k_ms = st.path_ms / launches
@@ -224,11 +220,9 @@ def main():
         n_pixels_rank = float(st.samples) / max(1, spp * a.steps)   # stats cover the timed steps
         if fused:      # per pixel and launch only; nothing per sample reaches memory
             unit_bytes = BATCH_PIXEL_BYTES * (n_pixels_rank / max(1, int(st.streams))) / max(units_per_launch, 1.0)
-        elif pipeline:
-            unit_bytes = SHADOW_RECORD_BYTES + SHADOW_PIXEL_BYTES * n_pixels_rank / max(units_per_launch, 1.0)
         else:
             unit_bytes = PIXEL_SAMPLE_BYTES
-        rays_per_launch = (float(st.shadow_rays) if pipeline else rays_k) / launches
+        rays_per_launch = rays_k / launches
         bytes_per_launch = (unit_bytes * units_per_launch + n_tri * TRI_REC_BYTES
                             + n_sph * SPH_BYTES)
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -262,7 +256,7 @@ def main():
                          "bytes_per_launch": bytes_per_launch,
                          "pixel_samples_per_launch": units_per_launch,
                          "rays_per_launch": rays_per_launch,
-                         "concurrent_streams": 2 if pipeline else int(st.streams),
+                         "concurrent_streams": int(st.streams),
                          "samples_per_launch_per_pixel": units_per_launch / max(1.0, n_pixels_rank / max(1, int(st.streams))) if fused else None,
                          "note": "the path is bound by VALU issue and scalar-load latency of the "
                                  "tree traversal, not by HBM (DESIGN.md); HBM fraction reported "
@@ -276,14 +270,6 @@ def main():
         # committed SQ_INSTS_VALU pass (same command, profiles/), the duration is live; a
         # wave64 VALU instruction occupies its SIMD for VALU_CYCLES, and the streams' launches
         # share the chip.
-        if pipeline:
-            out["primary_kernel"] = {"kernel": "k_primary", "launches_timed": int(st.primary_launches),
-                                     "avg_launch_ms": st.primary_ms / max(1, st.primary_launches),
-                                     "note": "closest hits of the camera rays of a whole batch of samples, "
-                                             "traced from predicted RNG counters (k_primary, then "
-                                             "k_primary_hard for the pixels the prediction failed on; "
-                                             "timed together); runs a batch ahead of k_shadow on its "
-                                             "own stream"}
         valu = measured_counter(cfg.name, kernel, "SQ_INSTS_VALU")
         if valu and k_ms > 0:
             prop = torch.cuda.get_device_properties(dev)
@@ -293,14 +279,6 @@ def main():
                 # every stream's launches share the chip: all instructions of the step against its wall time
                 frac = valu * float(launches) / a.steps * VALU_CYCLES / (dt / a.steps * simds * clk_hz)
                 insts = valu
-            elif pipeline:
-                # k_primary and k_shadow overlap on two streams: price both kernels'
-                # instructions of one batch against the wall time of one batch
-                valu_p = ((measured_counter(cfg.name, "k_primary", "SQ_INSTS_VALU") or 0.0) +
-                          (measured_counter(cfg.name, "k_primary_hard", "SQ_INSTS_VALU") or 0.0))
-                batch_s = dt / max(1.0, float(launches))
-                frac = (valu + valu_p) * VALU_CYCLES / (batch_s * simds * clk_hz)
-                insts = valu + valu_p
             else:
                 share = max(1, int(st.streams))
                 frac = valu * VALU_CYCLES / (k_ms * 1e-3 * simds * clk_hz / share)

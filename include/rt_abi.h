@@ -83,18 +83,15 @@ typedef struct rt_stats {
     uint64_t primary_rays;   /* camera rays                                         */
     uint64_t shadow_rays;    /* shadow rays actually cast (Scene.cu:224-225)        */
     uint64_t bounce_rays;    /* rays of bounces >= 1 whose hit is used              */
-    uint64_t path_launches;  /* launches of the dominant kernel: k_shadow (max_depth 0, one per
-                                batch of samples) or k_path (one per sample per stream)      */
+    uint64_t path_launches;  /* launches of the dominant kernel: k_batch (max_depth 0 over a deep tree: one
+                                per batch of samples and stream) or k_path (one per sample and stream) */
     double path_ms;          /* their summed HIP-event duration (timing mode only)  */
     double render_ms;        /* HIP-event duration of whole rt_render calls         */
     uint64_t n_prims;        /* triangles + quadrics of the uploaded scene          */
     uint64_t streams;        /* HIP streams the partition's pixel ranges render on   */
-    uint64_t primary_launches; /* launches of k_primary (max_depth 0), timing mode only */
-    double primary_ms;       /* their summed HIP-event duration                       */
     uint64_t coop_chunks;    /* k_path chunks run in the cooperative form (four waves sharing the
                                 traversals of one chunk; max_depth > 0 over a deep tree)        */
-    uint64_t batch_launches; /* launches of k_batch (max_depth 0 over a deep tree: one per batch of
-                                samples and stream); they are the path_launches then           */
+    uint64_t batch_launches; /* how many of the path_launches were k_batch                           */
 } rt_stats;
 
 /* Replaces the surface/graph set-up of initCUDA (kernel.cu:193-256): creates the

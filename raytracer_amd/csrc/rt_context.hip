@@ -86,7 +86,6 @@ struct rt_context {
     std::vector<void *> allocs;          // everything freed by rt_destroy
     std::vector<void *> scene_allocs;    // freed on re-upload
     std::vector<void *> part_allocs;     // freed on re-partition
-    std::vector<void *> batch_allocs;    // record buffers of the depth-0 pipeline: freed when outgrown or on re-partition
 
     int rank = 0, world = 1, tile = 64;
     uint32_t n_local = 0;
@@ -104,23 +103,9 @@ struct rt_context {
     DevView v{};                         // scene + per-pixel state
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
 
-    // depth-0 pipeline (k_primary -> k_shadow, rt_kernels.hip): `whole` spans the
-    // partition and carries k_primary's dispensers and feedback; k_shadow has its own control
-    // block; two record buffers alternate by batch; stream / events as long as the context
-    Lane whole;
-    Ctl *shade_ctl = nullptr;
-    uint32_t shade_seq = 0;
-    hipStream_t st_shade = nullptr;
-    hipEvent_t ev_prim_done[2] = {nullptr, nullptr}, ev_shade_done[2] = {nullptr, nullptr};
-    SampleBatch batch[2]{};
-    uint32_t batch_cap = 0;              // samples per record buffer
+    // depth 0 over a deep tree (k_batch, rt_kernels.hip): samples per batch
     int batch_wanted = 64;
-    bool fused = true;                   // depth 0 over a deep tree: one k_batch per batch (RT_FUSED=0: the three-kernel pipeline)
     uint64_t batch_launches = 0;         // launches of k_batch
-    uint64_t primary_launches = 0;
-    double primary_ms = 0.0;
-    std::vector<hipEvent_t> ev_pool2;    // (start, stop) pairs around k_primary launches
-    size_t ev_used2 = 0;
 
     // stats
     uint64_t samples = 0, primary = 0, launches = 0, timed_launches = 0;
@@ -235,7 +220,6 @@ int alloc_feedback(rt_context *c, Lane &L)
 int setup_partition(rt_context *c)
 {
     free_all(c->part_allocs);
-    free_all(c->batch_allocs);
     build_pixmap(c);
     const size_t n = c->n_local;
     DevView &v = c->v;
@@ -269,47 +253,6 @@ int setup_partition(rt_context *c)
         RT_HIP(c, hipMemset(L.ctl, 0, sizeof(Ctl)));
         if ((rc = alloc_feedback(c, L))) return rc;
     }
-    Lane &W = c->whole;
-    W.lo = 0; W.hi = (uint32_t)n; W.seq = 0;
-    if ((rc = dalloc(c, c->part_allocs, W.ctl, 1))) return rc;
-    RT_HIP(c, hipMemset(W.ctl, 0, sizeof(Ctl)));
-    if ((rc = dalloc(c, c->part_allocs, c->shade_ctl, 1))) return rc;
-    RT_HIP(c, hipMemset(c->shade_ctl, 0, sizeof(Ctl)));
-    c->shade_seq = 0;
-    c->batch_cap = 0;                    // record buffers went with part_allocs
-    c->batch[0].hard_q = c->batch[1].hard_q = nullptr;
-    return RT_OK;
-}
-
-// Record buffers of the depth-0 pipeline for batches of up to `cap` samples.  A set that has
-// been outgrown is freed before the larger one is allocated (the streams are idle here: every
-// rt_render ends with a synchronisation), and so is a set whose allocation failed half way.
-int ensure_batches(rt_context *c, uint32_t cap)
-{
-    if (cap <= c->batch_cap) return RT_OK;
-    // unit-major records (rt_kernels.hip rec_index): whole units of 128 pixel-samples
-    uint32_t ss = 1;
-    while (ss < cap) ss *= 2;
-    const size_t n = (size_t)c->n_local * ss + 128;
-    if (!c->batch[0].hard_q) {           // one queue: k_primary launches follow each other on one stream
-        int rc = dalloc(c, c->part_allocs, c->batch[0].hard_q, (size_t)c->n_local);
-        if (rc == RT_OK) rc = dalloc(c, c->part_allocs, c->batch[0].hard_cnt, 2);
-        if (rc) return rc;
-        c->batch[1].hard_q = c->batch[0].hard_q;
-        c->batch[1].hard_cnt = c->batch[0].hard_cnt;
-    }
-    free_all(c->batch_allocs);
-    c->batch_cap = 0;
-    for (int b = 0; b < 2; b++) {
-        for (int k = 0; k < 8; k++) {
-            int rc = dalloc(c, c->batch_allocs, c->batch[b].f[k], n);
-            if (rc) {
-                free_all(c->batch_allocs);
-                return rc;
-            }
-        }
-    }
-    c->batch_cap = cap;
     return RT_OK;
 }
 
@@ -351,25 +294,6 @@ void resolve_events(rt_context *c)
         }
     }
     c->ev_used = 0;
-    for (size_t k = 0; k + 1 < c->ev_used2; k += 2) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, c->ev_pool2[k], c->ev_pool2[k + 1]) == hipSuccess) {
-            c->primary_ms += ms;
-            c->primary_launches++;
-        }
-    }
-    c->ev_used2 = 0;
-}
-
-hipEvent_t next_event2(rt_context *c)
-{
-    if (c->ev_used2 == c->ev_pool2.size()) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess)
-            return nullptr;
-        c->ev_pool2.push_back(e);
-    }
-    return c->ev_pool2[c->ev_used2++];
 }
 
 // Feedback sets rotate by launch: read what the previous launch wrote, write the next set,
@@ -465,17 +389,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
             break;
         }
     }
-    if (rc == RT_OK) {
-        bool ok = hipStreamCreateWithFlags(&c->whole.stream, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&c->whole.done, hipEventDisableTiming) == hipSuccess &&
-                  hipStreamCreateWithFlags(&c->st_shade, hipStreamNonBlocking) == hipSuccess;
-        for (int b = 0; b < 2 && ok; b++)
-            ok = hipEventCreateWithFlags(&c->ev_prim_done[b], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&c->ev_shade_done[b], hipEventDisableTiming) == hipSuccess;
-        if (!ok) rc = fail(c, RT_ERR_DEVICE, "rt_create: could not create pipeline streams");
-    }
     if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(64, std::atoi(e)));
-    if (const char *e = std::getenv("RT_FUSED")) c->fused = std::atoi(e) != 0;
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -492,7 +406,6 @@ extern "C" int rt_destroy(rt_context *c)
     if (!c) return RT_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    free_all(c->batch_allocs);
     free_all(c->part_allocs);
     free_all(c->scene_allocs);
     free_all(c->allocs);
@@ -501,16 +414,6 @@ extern "C" int rt_destroy(rt_context *c)
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    if (c->whole.stream) (void)hipStreamSynchronize(c->whole.stream);
-    if (c->st_shade) (void)hipStreamSynchronize(c->st_shade);
-    if (c->whole.done) (void)hipEventDestroy(c->whole.done);
-    for (int b = 0; b < 2; b++) {
-        if (c->ev_prim_done[b]) (void)hipEventDestroy(c->ev_prim_done[b]);
-        if (c->ev_shade_done[b]) (void)hipEventDestroy(c->ev_shade_done[b]);
-    }
-    if (c->whole.stream) (void)hipStreamDestroy(c->whole.stream);
-    if (c->st_shade) (void)hipStreamDestroy(c->st_shade);
-    for (hipEvent_t e : c->ev_pool2) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_r0) (void)hipEventDestroy(c->ev_r0);
     if (c->ev_r1) (void)hipEventDestroy(c->ev_r1);
@@ -622,7 +525,7 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
     hipStream_t s0 = c->stream;
-    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3 && c->fused) {
+    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3) {
         // Depth 0 over a deep tree, one kernel per batch of samples and lane (k_batch,
         // rt_kernels.hip): camera rays from predicted counters, shadow rays and the running mean
         // of a unit without leaving the wave.  The lanes' launches follow each other on their own
@@ -656,55 +559,6 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             RT_HIP(c, hipEventRecord(c->lanes[k].done, c->lanes[k].stream));
             RT_HIP(c, hipStreamWaitEvent(s0, c->lanes[k].done, 0));
         }
-    } else if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3) {
-        // Depth 0 over a deep tree (a shallow one has no costly chunks to wait for, and the
-        // single path kernel moves fewer bytes): primary hits of a batch of samples on one stream, their shadow rays and
-        // the accumulation on a second one, a batch behind (rt_kernels.hip, "depth 0 in
-        // three kernels").  Two record buffers alternate; a buffer is refilled only after
-        // its shadow pass has finished.
-        // the largest batch (64, 32, 16 samples) that still leaves two batches to overlap
-        const int want = n_samples >= 128 ? 64 : n_samples >= 64 ? 32 : 16;
-        const uint32_t cap = (uint32_t)std::min(std::max(n_samples, 1), std::min(c->batch_wanted, want));
-        int rc = ensure_batches(c, cap);
-        if (rc) return rc;
-        hipStream_t sa = c->whole.stream, sb = c->st_shade;
-        RT_HIP(c, hipEventRecord(c->ev_r0, s0));
-        RT_HIP(c, hipStreamWaitEvent(sa, c->ev_r0, 0));
-        RT_HIP(c, hipStreamWaitEvent(sb, c->ev_r0, 0));
-        Lane &W = c->whole;
-        int k = 0;
-        for (int done = 0; done < n_samples; k++) {
-            const uint32_t S = (uint32_t)std::min<int>((int)cap, n_samples - done);
-            const int b = k & 1;
-            if (k >= 2)
-                RT_HIP(c, hipStreamWaitEvent(sa, c->ev_shade_done[b], 0));
-            hipEvent_t p0 = nullptr, p1 = nullptr, e0 = nullptr, e1 = nullptr;
-            if (c->timing) { p0 = next_event2(c); p1 = next_event2(c); e0 = next_event(c); e1 = next_event(c); }
-            if (p0) (void)hipEventRecord(p0, sa);
-            launch_primary(sa, c->v, c->n_local, S, c->batch[b], c->max_blocks, W.ctl,
-                           W.ctl->work[W.seq & 1u], W.ctl->work[(W.seq + 1u) & 1u]);
-            W.seq++;
-            if (p1) (void)hipEventRecord(p1, sa);
-            RT_HIP(c, hipEventRecord(c->ev_prim_done[b], sa));
-            RT_HIP(c, hipStreamWaitEvent(sb, c->ev_prim_done[b], 0));
-            if (e0) (void)hipEventRecord(e0, sb);
-            launch_shadow(sb, c->v, c->n_local, S, c->batch[b], c->cnt, c->max_blocks, c->shade_ctl,
-                          c->shade_ctl->work[c->shade_seq & 1u], c->shade_ctl->work[(c->shade_seq + 1u) & 1u]);
-            c->shade_seq++;
-            if (e1) (void)hipEventRecord(e1, sb);
-            RT_HIP(c, hipEventRecord(c->ev_shade_done[b], sb));
-            c->launches++;
-            c->cnt += (int)S;
-            done += (int)S;
-            c->samples += (uint64_t)c->n_local * S;
-            c->primary += (uint64_t)c->n_local * S;
-        }
-        RT_HIP(c, hipEventRecord(W.done, sa));
-        RT_HIP(c, hipStreamWaitEvent(s0, W.done, 0));
-        if (k > 0)
-            RT_HIP(c, hipStreamWaitEvent(s0, c->ev_shade_done[(k - 1) & 1], 0));
-        if (k > 1)
-            RT_HIP(c, hipStreamWaitEvent(s0, c->ev_shade_done[k & 1], 0));
     } else {
     RT_HIP(c, hipEventRecord(c->ev_r0, s0));                 // fork: lanes start after the main stream
     for (int k = 0; k < c->n_lanes; k++)
@@ -917,8 +771,6 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     unsigned long long shadow_total = 0, bounce_total = 0, coop_total = 0;
     std::vector<Ctl *> ctls;
     for (int k = 0; k < c->n_lanes; k++) ctls.push_back(c->lanes[k].ctl);
-    ctls.push_back(c->whole.ctl);
-    ctls.push_back(c->shade_ctl);
     for (Ctl *p : ctls) {
         Ctl h;
         RT_HIP(c, hipMemcpy(&h, p, sizeof(Ctl), hipMemcpyDeviceToHost));
@@ -935,8 +787,6 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->render_ms = c->render_ms;
     st->n_prims = c->n_prims;
     st->streams = (uint64_t)c->n_lanes;
-    st->primary_launches = c->primary_launches;
-    st->primary_ms = c->primary_ms;
     st->coop_chunks = coop_total;
     st->batch_launches = c->batch_launches;
     return RT_OK;
@@ -951,13 +801,7 @@ extern "C" int rt_reset_stats(rt_context *c)
         RT_HIP(c, hipMemset(c->lanes[k].ctl, 0, sizeof(Ctl)));
         c->lanes[k].seq = 0;
     }
-    RT_HIP(c, hipMemset(c->whole.ctl, 0, sizeof(Ctl)));
-    c->whole.seq = 0;
-    RT_HIP(c, hipMemset(c->shade_ctl, 0, sizeof(Ctl)));
-    c->shade_seq = 0;
-    c->primary_launches = 0;
     c->batch_launches = 0;
-    c->primary_ms = 0.0;
     c->samples = c->primary = c->launches = c->timed_launches = 0;
     c->path_ms = c->render_ms = 0.0;
     return RT_OK;

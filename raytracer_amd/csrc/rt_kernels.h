@@ -83,21 +83,10 @@ struct DevView {
     // persistent per local pixel
     const uint32_t *pixmap;         // local index -> global pixel index y*W + x
     uint32_t *rng_ctr;              // next Philox draw of the pixel's stream
-    uint32_t *last_draws;           // draws the pixel's latest depth-0 batch sample consumed (0: none yet); k_primary predicts from it
+    uint32_t *last_draws;           // draws the pixel's latest depth-0 batch sample consumed (0: none yet); k_batch predicts from it
     float4 *fb;                     // RGBA32F running mean
     int32_t *first_id;
     float *first_t;
-};
-
-// Records of one batch of samples of the depth-0 pipeline (k_primary -> k_shadow),
-// struct-of-arrays, unit-major: the 128 pixel-samples a wave works on are contiguous in every
-// array (rt_kernels.hip rec_index).
-//   f[0..2] hit position
-//   f[3..5] normal   f[6] dot(-dir, normal)   f[7] model index as int bits, -1 = the ray missed
-struct SampleBatch {
-    float *f[8];
-    uint4 *hard_q;                  // k_primary's queue of pixels whose samples flip outcome: one entry per pixel
-    uint32_t *hard_cnt;             // [0] queued, [1] taken
 };
 
 // One progressive sample of local pixels [p0, p0 + n): the whole path of every pixel
@@ -108,16 +97,9 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
                  const ChunkFeedback *fb);
 constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (two per lane)
 
-// Depth-0 pipeline over the whole partition (n pixels), one batch of n_samples samples.
-void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next);
-void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                   const SampleBatch &b, int cnt0, int max_blocks, Ctl *ctl, uint32_t *work,
-                   uint32_t *work_next);
-
-// The same in ONE kernel per batch, over local pixels [p0, p0 + n): camera rays, the pixels the
-// prediction fails on, shadow rays and the running mean without leaving the wave (k_batch).
+// Depth 0 over a deep tree, one batch of n_samples samples of local pixels [p0, p0 + n) in ONE
+// kernel: camera rays from predicted counters, the pixels the prediction fails on, shadow rays
+// and the running mean without leaving the wave (k_batch).
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
                   int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next);
 

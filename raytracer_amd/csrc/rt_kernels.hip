@@ -891,63 +891,43 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
         [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
 }
 
-// ------------------------------------------------------------------ depth 0: a pipeline over batches
+// ------------------------------------------------------------------ depth 0: whole batches of samples
 // With max_depth = 0 (primary hit + direct light, the benchmark mode) the samples of a pixel
 // depend on one another only through the closest hit of the camera ray: the pixel's Philox
 // counter advances by 1 (jitter) + 1 (PathTracer.cu:27) + one per light if the ray hit
 // (Scene.cu:87) + 1 if the BRDF sample is usable (PathTracer.cu:77, the discarded trace of the
 // next iteration).  The shadow rays -- most of the work -- do not feed back into it, and the
-// count itself rarely changes from one sample of a pixel to the next.  So, per batch of S
-// samples (16, 32 or 64), a wave working on px pixels x ss samples = 128 rays:
-//   k_primary       camera rays of all samples at once from PREDICTED counters, checked
-//                   afterwards; one 32-byte hit record per pixel-sample
-//   k_primary_hard  the few pixels the prediction fails on, by enumeration of their counters
-//   k_shadow        lights, shadow rays, radiance of every sample, and the pixels' running
-//                   mean in sample order (kernel.cu:65-66,75,77)
-// k_shadow of one batch overlaps k_primary of the next on a second stream; a step is as
-// long as its throughput allows, not spp times its costliest chunk (Multi-GPU).
+// count itself rarely changes from one sample of a pixel to the next.  So rt_render(n, 0) over a
+// deep tree works in batches of S samples (16 or 32), and a wave takes a UNIT of px pixels x ss
+// samples = 128 rays (ss = 2^ss_log2 >= S: 8 x 16, 4 x 32, 2 x 64) through three phases (k_batch,
+// fused_unit below):
+//   P  camera rays of all samples at once from PREDICTED counters: every sample's counter is
+//      predicted from its pixel's expected draws per sample (round 0: what the pixel's last sample
+//      did; round 1: the same, or what the mispredicted sample did if that was the pixel's first),
+//      all are traced together, and the prediction is checked pixel by pixel: the samples up to
+//      and including the first whose draw count differs were traced from the counter the
+//      sequential order gives them and are final.
+//   H  pixels still open after two rounds flip between outcomes from sample to sample
+//      (silhouettes, ~1 % of the pixels).  Their next 8 samples can only start at the counters
+//      base + 2 a + (2 + lights) b + (3 + lights) c, a + b + c < 8 -- 120 candidates -- so the wave
+//      traces ALL of them for the one pixel at once and then walks the chain through the table:
+//      eight samples per round, so two rounds settle a batch of 16, four one of 32.
+//   S  lights, shadow rays, radiance of every sample, and the pixels' running mean in sample
+//      order (kernel.cu:65-66,75,77).
+// Every record was computed from the exact counter of the reference's order, so the result is
+// bit-identical to sample-after-sample; only the chain of spp dependent traversals is gone: no
+// pixel needs more than 2 + ss / 8 (Multi-GPU).
 struct BatchArgs {
     DevView v;
     TravArgs T;
-    uint32_t p0, n;                  // local pixels [p0, p0 + n) (k_primary / k_shadow: p0 = 0, the partition)
+    uint32_t p0, n;                  // this launch renders local pixels [p0, p0 + n)
     uint32_t n_samples;              // samples in this batch
-    SampleBatch b;
-    uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2): fixes the record layout
-    uint4 *hard_q;                   // k_primary -> k_primary_hard: (pixel, first open sample, its counter, -)
-    uint32_t *hard_cnt;              // [0] entries queued, [1] entries taken
-    int cnt0;                        // k_shadow: samples accumulated before this batch
+    uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2)
+    int cnt0;                        // samples accumulated before this batch
     bool occlusion;
     Ctl *ctl;
 };
 
-// Element of the record arrays that holds sample s of local pixel p: unit-major -- the 128
-// pixel-samples (px pixels x ss samples) a wave of k_primary / k_shadow works on are
-// 512 contiguous bytes of every array.
-__device__ __forceinline__ size_t rec_index(uint32_t ss_log2, uint32_t p, uint32_t s)
-{
-    const uint32_t px_log2 = 7u - ss_log2;
-    return ((size_t)(p >> px_log2) << 7) + (s << px_log2) + (p & ((1u << px_log2) - 1u));
-}
-
-// k_primary, all samples of a batch at once.  The samples of a pixel are chained only through
-// the NUMBER of draws each one consumes: 2 on a miss, 2 + lights on a hit, +1 if the hit's BRDF
-// sample is usable (PathTracer.cu:77) -- and that number is almost always the one of the sample
-// before.  Two kernels:
-//   k_primary  a wave takes px pixels x ss samples (ss = 2^ss_log2 >= n_samples: 8 x 16,
-//     4 x 32 or 2 x 64).  Every sample's counter is PREDICTED from its pixel's expected draws
-//     per sample (round 0: what the pixel's last sample did; round 1: the same, or what the
-//     mispredicted sample did if that was the pixel's first), all are traced together, and the prediction is checked pixel by
-//     pixel: the samples up to and including the first whose draw count differs were traced
-//     from the counter the sequential order gives them and are final.  Pixels still open
-//     after two rounds flip between outcomes from sample to sample (silhouettes, ~1 % of the
-//     pixels): they go to a queue.
-//   k_primary_hard   one queued pixel per wave.  The next 8 samples can only start at the
-//     counters base + 2 a + (2 + lights) b + (3 + lights) c, a + b + c < 8 -- 120 candidates --
-//     so the wave traces ALL of them for the one pixel at once and then walks the chain through
-//     the table: eight samples per round, so two rounds settle a batch of 16, eight one of 64.
-// Every record that is written was computed from the exact counter of the reference's order, so
-// the result is bit-identical to sample-after-sample; only the chain of spp dependent
-// traversals is gone: no pixel needs more than 2 + ss / 8 (Multi-GPU).
 // What a lane carries across a traversal is parked in LDS (slot i of a lane: st[i * kBlock]),
 // as in the path kernel: the closest-hit traversal needs the register file to itself, and what
 // the compiler would otherwise spill goes to scratch memory and from there to HBM.
@@ -1030,144 +1010,6 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
     }
 }
 
-// The record of sample s of local pixel p, traced from counter ctr.
-__device__ __forceinline__ void write_primary(const BatchArgs &A, const PrimaryTrace &o, int h,
-                                              uint32_t s, uint32_t p, uint32_t ctr)
-{
-    const size_t i = rec_index(A.ss_log2, p, s);
-#pragma unroll
-    for (int k = 0; k < 7; k++)
-        A.b.f[k][i] = o.rec[h][k];
-    A.b.f[7][i] = __int_as_float(o.model[h]);
-    if (s + 1u == A.n_samples) {                             // id / t buffers: the last sample's primary hit
-        A.v.first_id[p] = o.id[h];
-        A.v.first_t[p] = o.t[h];
-        A.v.rng_ctr[p] = ctr + o.delta[h];
-        A.v.last_draws[p] = o.delta[h];
-    }
-}
-
-template <bool CULL>
-__device__ __forceinline__ void primary_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                             uint32_t lane, uint32_t *st, Stamps &sp)
-{
-    RT_MARK(sp, 1);
-    RT_COUNT(sp, 11);
-    const DevView &v = A.v;
-    const uint32_t L = (uint32_t)v.n_lights;
-    const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u, ss = 1u << A.ss_log2;
-    uint32_t cost = 0;
-    uint32_t pix[2], base_c[2], base_s[2], dhat[2];
-    bool todo[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t r = (uint32_t)h * 64u + lane;
-        const uint32_t pl = (unit << px_log2) + (r & px_mask);
-        todo[h] = pl < A.n && (r >> px_log2) < A.n_samples;
-        const uint32_t p = min(pl, A.n - 1u);
-        pix[h] = v.pixmap[p];
-        base_c[h] = v.rng_ctr[p];
-        base_s[h] = 0u;
-        // expected draws per sample: what the pixel's last sample before this batch consumed,
-        // a hit's when there is none yet (a wrong guess costs the pixel one more round)
-        const uint32_t last = v.last_draws[p];
-        dhat[h] = last ? last : 3u + L;
-    }
-    for (int round = 0; round < 2; round++) {
-        if (!__ballot(todo[0] | todo[1]))
-            return;
-        uint32_t ctr[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t smp = ((uint32_t)h * 64u + lane) >> px_log2;
-            ctr[h] = base_c[h] + (smp - base_s[h]) * dhat[h];
-            st[(5 + h) * kBlock] = base_c[h];
-            st[(7 + h) * kBlock] = base_s[h];
-            st[(9 + h) * kBlock] = dhat[h];
-        }
-        PrimaryTrace o;
-        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, st, sp);
-        uint32_t q[2], smp[2], p[2];
-        uint32_t ln = lane;
-        asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t r = (uint32_t)h * 64u + ln;
-            q[h] = r & px_mask;
-            smp[h] = r >> px_log2;
-            p[h] = min((unit << px_log2) + q[h], A.n - 1u);
-            base_c[h] = st[(5 + h) * kBlock];
-            base_s[h] = st[(7 + h) * kBlock];
-            dhat[h] = st[(9 + h) * kBlock];
-        }
-        // first sample of each pixel whose draw count is not the expected one
-        const unsigned long long m0 = __ballot(todo[0] && o.delta[0] != dhat[0]);
-        const unsigned long long m1 = __ballot(todo[1] && o.delta[1] != dhat[1]);
-        uint32_t first[2], src[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            first[h] = ss;
-            for (uint32_t k = ss; k-- > 0u;) {
-                const uint32_t r = (k << px_log2) + q[h];
-                const bool bit = (((r < 64u ? m0 : m1) >> (r & 63u)) & 1ull) != 0ull;
-                first[h] = bit ? k : first[h];
-            }
-            src[h] = (min(first[h], ss - 1u) << px_log2) + q[h];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            // its draw count, from the lane that holds it
-            const uint32_t lo = (uint32_t)__shfl((int)o.delta[0], (int)(src[h] & 63u));
-            const uint32_t hi = (uint32_t)__shfl((int)o.delta[1], (int)(src[h] & 63u));
-            const uint32_t dj = src[h] < 64u ? lo : hi;
-            if (todo[h] && smp[h] <= first[h]) {             // traced from the right counter: final
-                write_primary(A, o, h, smp[h], p[h], ctr[h]);
-                todo[h] = false;
-            }
-            if (first[h] < ss) {                             // the pixel goes on from behind sample `first`
-                // ... expecting what it expected before, unless its very first open sample
-                // was the odd one (then the pixel as a whole has changed: expect that instead)
-                const bool changed = first[h] == base_s[h];
-                base_c[h] += (first[h] - base_s[h]) * dhat[h] + dj;
-                base_s[h] = first[h] + 1u;
-                dhat[h] = changed ? dj : dhat[h];
-            }
-            // still open after the second round: the lane of a pixel's first open sample queues the pixel
-            if (round == 1 && todo[h] && smp[h] == base_s[h]) {
-                const uint32_t slot = atomicAdd(&A.hard_cnt[0], 1u);
-                A.hard_q[slot] = make_uint4(p[h], base_s[h], base_c[h], 0u);
-            }
-        }
-    }
-}
-
-template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_primary(const BatchArgs A, uint32_t *__restrict__ work,
-                                                             uint32_t *__restrict__ work_next, int dynamic)
-{
-    __shared__ uint32_t s_chunk;
-    __shared__ uint32_t s_stash[kPrimSlots][kBlock];
-    uint32_t *st = &s_stash[0][threadIdx.x];
-    const uint32_t lane = threadIdx.x & 63u;
-    ChunkEnv env;
-    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
-    const ChunkFeedback none{};
-    const uint32_t px = kPathChunk >> A.ss_log2;
-    Stamps sp;
-#ifdef RT_STAMPS
-    sp.start();
-    const unsigned long long t_begin = sp.last;
-#endif
-    run_chunks<CULL>(
-        (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t unit) { primary_unit<CULL>(A, env, unit, lane, st, sp); RT_MARK(sp, 10); },
-        [&](uint32_t) {});
-#ifdef RT_STAMPS
-    sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
-    sp.flush(0);
-#endif
-}
-
 // Candidate r of the table: level k = samples before it, of which b hits without and c hits with
 // a usable BRDF sample.  Levels start at k (k + 1) (k + 2) / 6; inside a level, t = b + c,
 // index t (t + 1) / 2 + c.
@@ -1189,258 +1031,9 @@ __device__ __forceinline__ void hard_candidate(uint32_t r, uint32_t &k, uint32_t
     if (r >= hard_level_off(kHardLevels)) k = kHardLevels;
 }
 
-template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_primary_hard(const BatchArgs A)
-{
-    __shared__ uint32_t s_stash[kPrimSlots][kBlock];
-    uint32_t *st = &s_stash[0][threadIdx.x];
-    const DevView &v = A.v;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t L = (uint32_t)v.n_lights;
-    ChunkEnv env;
-    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
-    const uint32_t count = min(A.hard_cnt[0], A.n);
-    uint32_t cost = 0;
-    for (;;) {
-        uint32_t item = 0;
-        if (lane == 0)
-            item = atomicAdd(&A.hard_cnt[1], 1u);
-        item = (uint32_t)__builtin_amdgcn_readfirstlane(item);
-        if (item >= count)
-            return;
-        const uint4 e = A.hard_q[item];
-        const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane(e.x);
-        uint32_t e_s = (uint32_t)__builtin_amdgcn_readfirstlane(e.y);
-        uint32_t e_c = (uint32_t)__builtin_amdgcn_readfirstlane(e.z);
-        const uint32_t pix1 = v.pixmap[p];
-        for (int round = 0; round < 16 && e_s < A.n_samples; round++) {
-            const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);
-            uint32_t pix[2] = {pix1, pix1}, ctr[2];
-            bool live[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                uint32_t k, a, b, c;
-                hard_candidate((uint32_t)h * 64u + lane, k, a, b, c);
-                live[h] = k < e_n;
-                ctr[h] = e_c + 2u * a + (2u + L) * b + (3u + L) * c;
-            }
-            PrimaryTrace o;
-            Stamps sp0;
-            trace_primary<CULL>(A, env, lane, pix, ctr, live, o, cost, st, sp0);
-            const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
-            const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
-            const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
-            const unsigned long long b1 = __ballot(live[1] && o.delta[1] == 2u + L);
-            // walk the chain through the table (wave-uniform)
-            unsigned long long c0 = 0ull, c1 = 0ull;
-            uint32_t b = 0, c = 0, c_new = e_c;
-            for (uint32_t k = 0; k < e_n; k++) {
-                const uint32_t t = b + c;
-                const uint32_t r = hard_level_off(k) + t * (t + 1u) / 2u + c;
-                const unsigned long long bit = 1ull << (r & 63u);
-                if (r < 64u) c0 |= bit; else c1 |= bit;
-                if (((r < 64u ? u0 : u1) & bit) != 0ull)      { c_new += 3u + L; c++; }
-                else if (((r < 64u ? b0 : b1) & bit) != 0ull) { c_new += 2u + L; b++; }
-                else                                          { c_new += 2u; }
-            }
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-                if ((((h ? c1 : c0) >> lane) & 1ull) != 0ull) {
-                    uint32_t k, ca, cb, cc;
-                    hard_candidate((uint32_t)h * 64u + lane, k, ca, cb, cc);
-                    write_primary(A, o, h, e_s + k, p, ctr[h]);
-                }
-            e_s += e_n;
-            e_c = c_new;
-        }
-    }
-}
-
-// One unit = 128 pixel-samples = px consecutive pixels (a compact patch of the image) x ss
-// consecutive samples of the batch, ss = 2^ss_log2 <= 64: the shadow rays of one pixel's
-// samples towards a light differ only by the sub-pixel jitter, so packing samples instead of
-// more pixels into a wave shrinks the part of the tree the wave's rays visit together
-// (16 samples x 8 pixels against 1 x 128: C3 -27 % shadow time, C4 -40 %, C5 -68 %).
-template <bool CULL>
-__device__ __forceinline__ void shadow_chunk(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                             uint32_t lane, float *st, Stamps &sp)
-{
-    RT_MARK(sp, 1);
-    RT_COUNT(sp, 11);
-    using State = RayState<true>;
-    const DevView &v = A.v;
-    const int L = v.n_lights;
-    const float E = A.T.tv.extent;
-    const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u;
-    uint32_t cost = 0, n_shadow = 0;
-    State S[2];
-    bool hit[2], cast[2] = {false, false};
-    size_t idx[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t r = (uint32_t)h * 64u + lane;
-        const uint32_t pl = (unit << px_log2) + (r & px_mask), s = r >> px_log2;
-        idx[h] = ((size_t)unit << 7) + r;                    // rec_index(pl, s)
-        S[h] = State{};
-        S[h].model = (pl < A.n && s < A.n_samples) ? __float_as_int(A.b.f[7][idx[h]]) : -1;
-        hit[h] = S[h].model >= 0;
-        if (hit[h]) {
-            S[h].pos = mk3(A.b.f[0][idx[h]], A.b.f[1][idx[h]], A.b.f[2][idx[h]]);
-            S[h].normal = mk3(A.b.f[3][idx[h]], A.b.f[4][idx[h]], A.b.f[5][idx[h]]);
-            S[h].wo_y = A.b.f[6][idx[h]];
-        }
-        S[h].le = mk3(0.0f, 0.0f, 0.0f);
-    }
-#ifdef RT_STAMPS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    RT_MARK(sp, 2);
-#endif
-    RayPair w;
-    const int n_lights = __ballot(hit[0] | hit[1]) ? L : 0;  // nobody hit: nothing to light
-    for (int j = 0; j < n_lights; j++) {
-        // one point light against the hits: Scene.cu:83-120 -> evaluateDirectLight :205-224
-        const LightRec light = load_uniform(&v.lights[j]);
-        v3 so[2], sd[2];
-        float sb[2], ss[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            cast[h] = false;
-            so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
-            sb[h] = kInf; ss[h] = -1.0f;
-            if (hit[h]) {
-                LightSample ls = sample_point_light(S[h].hit(), v.models[S[h].model], S[h].wo_y, light);
-                cast[h] = ls.cast;
-                so[h] = ls.sr.o; sd[h] = ls.sr.d;
-                S[h].thr = fmaxf(ls.thr, 0.0f);              // Scene.cu:227 rhs
-                S[h].contrib = ls.contrib;
-                if (A.occlusion) {
-                    float m = 1e-4f * (fabsf(S[h].thr) + fabsf(so[h].x) + fabsf(so[h].y) + fabsf(so[h].z)) + 1e-6f;
-                    sb[h] = fminf(kInf, S[h].thr + m);
-                    ss[h] = S[h].thr - m;
-                }
-            }
-        }
-        const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
-        if (!(c0 | c1))
-            continue;                                        // nobody casts towards this light
-        n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
-        pair_set(w, so, sd, sb, ss, cast, E);
-        RT_MARK(sp, 3);
-        S[0].save(st);
-        S[1].save(st + State::kSlots * kBlock);
-        asm volatile("" ::: "memory");
-        RT_MARK(sp, 4);
-        traverse<CULL, false, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
-        asm volatile("" ::: "memory");
-        S[0].load(st);
-        S[1].load(st + State::kSlots * kBlock);
-#ifdef RT_STAMPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-        RT_MARK(sp, 4);
-        // Scene.cu:225-241: blocked = |light_rec.pos - r.o| < |r.o - lpos| - 0.01
-        // (H3: `lightidx == idx` restated as never true for point lights)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            if (!cast[h])
-                continue;
-            const float best = h ? w.best.y : w.best.x;
-            const int32_t sid = h ? w.idy : w.idx;
-            bool blocked = false;
-            if (scene_ishit(best) && sid >= 0) {
-                Ray sr;
-                sr.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
-                sr.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
-                v3 hp = sid < v.n_tris ? ray_pos(sr, best)
-                                       : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
-                blocked = length(sub(hp, sr.o)) < S[h].thr;
-            }
-            if (!blocked)                                    // res += ... in light order (Scene.cu:120)
-                S[h].le = add(S[h].le, S[h].contrib);
-        }
-    }
-    RT_MARK(sp, 3);
-    v3 res[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++)                              // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64)
-        res[h] = hit[h] ? add(mk3(0.0f, 0.0f, 0.0f), mul(mk3(1.0f, 1.0f, 1.0f), S[h].le)) : mk3(0.0f, 0.0f, 0.0f);
-    // kernel.cu:65-66,75,77: the running mean of each pixel, in sample order.  The wave holds all
-    // samples of its pixels; lane q < px owns pixel q and pulls sample s from the lane that has it.
-    if (px_log2 == 7u) {                                     // one sample: both pixels of a lane
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t pl = (unit << 7) + (uint32_t)h * 64u + lane;
-            if (pl < A.n && A.n_samples) {
-                const int cnt = A.cnt0 + 1;
-                const float frac1 = 1.0f / cnt, frac2 = frac1 * (cnt - 1);
-                float4 prev = v.fb[pl];
-                prev.x = frac2 * prev.x + frac1 * res[h].x;
-                prev.y = frac2 * prev.y + frac1 * res[h].y;
-                prev.z = frac2 * prev.z + frac1 * res[h].z;
-                prev.w = 1.0f;
-                v.fb[pl] = prev;
-            }
-        }
-    } else {
-        const uint32_t pl = (unit << px_log2) + lane;
-        const bool owner = lane <= px_mask && pl < A.n;
-        float4 prev = owner ? v.fb[pl] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (uint32_t smp = 0; smp < A.n_samples; smp++) {
-            const uint32_t r = (smp << px_log2) + (lane & px_mask);
-            const bool upper = (smp << px_log2) >= 64u;      // wave-uniform
-            const float rx = __shfl(upper ? res[1].x : res[0].x, (int)(r & 63u));
-            const float ry = __shfl(upper ? res[1].y : res[0].y, (int)(r & 63u));
-            const float rz = __shfl(upper ? res[1].z : res[0].z, (int)(r & 63u));
-            const int cnt = A.cnt0 + (int)smp + 1;
-            const float frac1 = 1.0f / cnt, frac2 = frac1 * (cnt - 1);
-            prev.x = frac2 * prev.x + frac1 * rx;
-            prev.y = frac2 * prev.y + frac1 * ry;
-            prev.z = frac2 * prev.z + frac1 * rz;
-            prev.w = 1.0f;
-        }
-        if (owner)
-            v.fb[pl] = prev;
-    }
-    if (lane == 0 && n_shadow)
-        atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
-#ifdef RT_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    RT_MARK(sp, 10);
-}
-
-template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_shadow(const BatchArgs A, uint32_t *__restrict__ work,
-                                                          uint32_t *__restrict__ work_next, int dynamic)
-{
-    __shared__ uint32_t s_chunk;
-    __shared__ float s_stash[2 * RayState<true>::kSlots][kBlock];
-    float *st = &s_stash[0][threadIdx.x];
-    const uint32_t lane = threadIdx.x & 63u;
-    ChunkEnv env;
-    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
-    const ChunkFeedback none{};
-    const uint32_t px = kPathChunk >> A.ss_log2;
-    Stamps sp;
-#ifdef RT_STAMPS
-    sp.start();
-    const unsigned long long t_begin = sp.last;
-#endif
-    run_chunks<CULL>(
-        (A.n + px - 1u) / px, none, 0u, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t unit) { shadow_chunk<CULL>(A, env, unit, lane, st, sp); },
-        [&](uint32_t) {});
-#ifdef RT_STAMPS
-    sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
-    sp.flush(1);
-#endif
-}
-
 // ------------------------------------------------------------------ depth 0, one kernel per batch
-// k_batch does for a unit (px pixels x ss samples = 128 rays of one wave) everything the three
-// kernels above do, without leaving the wave: camera rays from predicted counters (two rounds),
-// the pixels the prediction fails on by enumeration (the wave itself, one pixel at a time), then
-// lights, shadow rays and the pixels' running mean.  The hit records never reach memory: they
+// k_batch takes a unit (px pixels x ss samples = 128 rays of one wave) through phases P, H and S
+// without leaving the wave.  The hit records never reach memory: they
 // sit in LDS (8 dwords per ray, row-major by field, one column per lane) from the moment a
 // sample's camera ray is final until its shadow rays are done; a record traced by ANOTHER lane
 // (the enumeration walks one pixel's candidates on all lanes) is written straight into the
@@ -1491,7 +1084,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     RT_MARK(sp, 1);
     RT_COUNT(sp, 11);
 
-    // ---------------- phase P: the camera rays' closest hits (primary_unit, records to LDS)
+    // ---------------- phase P: the camera rays' closest hits, records to LDS
     uint32_t pix[2], base_c[2], base_s[2], dhat[2];
     bool todo[2];
 #pragma unroll
@@ -1570,7 +1163,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
     }
 
-    // ---------------- phase H: pixels still open after two rounds (k_primary_hard, on this wave)
+    // ---------------- phase H: pixels still open after two rounds, one at a time
     {
         uint32_t ln = lane;
         asm volatile("" : "+v"(ln));
@@ -1644,7 +1237,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 
-    // ---------------- phase S: lights, shadow rays, the pixels' running mean (shadow_chunk)
+    // ---------------- phase S: lights, shadow rays, the pixels' running mean
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
     const uint32_t own_pl = A.p0 + (unit << px_log2) + ln;
@@ -2078,54 +1671,17 @@ static uint32_t batch_grid(uint32_t units, uint32_t cap)
     return std::min<uint32_t>(std::max<uint32_t>(units / 96u, 1u), cap);
 }
 
-static BatchArgs batch_args(const DevView &v, uint32_t n, uint32_t n_samples, const SampleBatch &b, Ctl *ctl)
+static BatchArgs batch_args(const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples, int cnt0, Ctl *ctl)
 {
     BatchArgs A{};
     A.v = v;
     A.T = trav_args(v);
-    A.n = n; A.n_samples = n_samples;
+    A.p0 = p0; A.n = n; A.n_samples = n_samples;
     A.ss_log2 = batch_ss_log2(n_samples);
-    A.b = b;
-    A.hard_q = b.hard_q; A.hard_cnt = b.hard_cnt;
+    A.cnt0 = cnt0;
     A.occlusion = v.n_spheres == 0;
     A.ctl = ctl;
     return A;
-}
-
-void launch_primary(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                    const SampleBatch &b, int max_blocks, Ctl *ctl, uint32_t *work,
-                    uint32_t *work_next)
-{
-    if (n == 0 || n_samples == 0)
-        return;
-    BatchArgs A = batch_args(v, n, n_samples, b, ctl);
-    const int dynamic = v.cull && v.tree.top >= 3;
-    const uint32_t px = kPathChunk >> A.ss_log2;
-    const uint32_t units = (n + px - 1) / px;
-    const uint32_t cap = (uint32_t)std::max(max_blocks, 1) * 4u;
-    (void)hipMemsetAsync(A.hard_cnt, 0, 2 * sizeof(uint32_t), s);
-    const uint32_t g = batch_grid(units, cap);
-    k_primary<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);   // the pipeline runs with culling only (rt_render)
-    // the pixels it queued, one per wave (about 1 % of them, at silhouettes; the other waves leave at once)
-    if (n_samples > 1u) {
-        const uint32_t gh = std::min<uint32_t>(std::max<uint32_t>((n + 31u) / 32u, 1u), cap);
-        k_primary_hard<true><<<gh, kBlock, 0, s>>>(A);
-    }
-}
-
-void launch_shadow(hipStream_t s, const DevView &v, uint32_t n, uint32_t n_samples,
-                   const SampleBatch &b, int cnt0, int max_blocks, Ctl *ctl, uint32_t *work,
-                   uint32_t *work_next)
-{
-    if (n == 0 || n_samples == 0)
-        return;
-    BatchArgs A = batch_args(v, n, n_samples, b, ctl);
-    A.cnt0 = cnt0;
-    const int dynamic = v.cull && v.tree.top >= 3;
-    const uint32_t px = kPathChunk >> A.ss_log2;
-    const unsigned long long units = (n + px - 1) / px;
-    const uint32_t g = batch_grid((uint32_t)units, (uint32_t)std::max(max_blocks, 1) * 4u);
-    k_shadow<true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
 }
 
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
@@ -2133,10 +1689,7 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
 {
     if (n == 0 || n_samples == 0)
         return;
-    SampleBatch none{};
-    BatchArgs A = batch_args(v, n, n_samples, none, ctl);
-    A.p0 = p0;
-    A.cnt0 = cnt0;
+    BatchArgs A = batch_args(v, p0, n, n_samples, cnt0, ctl);
     const uint32_t px = kPathChunk >> A.ss_log2;
     const uint32_t units = (n + px - 1) / px;
     const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * 4u);

@@ -363,6 +363,8 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     c->v.width = width;
     c->v.height = height;
     c->v.cull = 1;
+    c->v.sorted_planes = 1;
+    if (const char *e = std::getenv("RT_SORTED")) c->v.sorted_planes = std::atoi(e) != 0;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&c->stream);
     if (e == hipSuccess) e = hipEventCreate(&c->ev_r0);

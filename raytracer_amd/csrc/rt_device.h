@@ -145,6 +145,8 @@ struct RayPair {
     f2 bestp;         // best * kBestInfl: conservative side of every pre-test
     f2 stop;          // shadow rays: a hit with t below this ends the ray (-1: never)
     int idx, idy;     // reference traversal index of the closest primitive, -1 = none
+    uint32_t oct;     // wave-uniform.  bit 3: every culled ray of the wave runs the same way along
+                      // every axis (they share an octant); bits 0-2: towards -x, -y, -z
 };
 
 constexpr float kBestInfl = 1.000004f;
@@ -180,6 +182,31 @@ __device__ __forceinline__ void node_test(const RayPair &r, float lx, float ly, 
     float tny = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), 0.0f));
     float tfx = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
     float tfy = fminf(fminf(fmaxf(ax.y, bx.y), fmaxf(ay.y, by.y)), fmaxf(az.y, bz.y));
+    tfx = fminf(tfx * kBestInfl, r.bestp.x);
+    tfy = fminf(tfy * kBestInfl, r.bestp.y);
+    px = !(tnx > tfx);
+    py = !(tny > tfy);
+    ex = tnx;
+    ey = tny;
+}
+
+// The same test when every culled ray of the wave shares an octant (RayPair::oct): which of a
+// box's two planes per axis a ray enters through is then known for the whole wave, so the planes
+// arrive already ordered -- n* the entry side, f* the exit side -- and the six min / max per ray
+// that sort them go away.  With 1/d > 0, fma(lo, 1/d, -o/d) <= fma(hi, 1/d, -o/d) (rounding is
+// monotone), so the near / far values are the ones node_test's min / max pick, bit for bit; rays
+// that are never culled (1/d = 0) and parked rays get the same value from both planes of an axis.
+__device__ __forceinline__ void node_test_sorted(const RayPair &r, float nx, float ny, float nz,
+                                                 float fx, float fy, float fz, bool &px, bool &py,
+                                                 float &ex, float &ey)
+{
+    f2 ax = __builtin_elementwise_fma(f2{nx, nx}, r.ix, -r.px), bx = __builtin_elementwise_fma(f2{fx, fx}, r.ix, -r.px);
+    f2 ay = __builtin_elementwise_fma(f2{ny, ny}, r.iy, -r.py), by = __builtin_elementwise_fma(f2{fy, fy}, r.iy, -r.py);
+    f2 az = __builtin_elementwise_fma(f2{nz, nz}, r.iz, -r.pz), bz = __builtin_elementwise_fma(f2{fz, fz}, r.iz, -r.pz);
+    float tnx = fmaxf(fmaxf(ax.x, ay.x), fmaxf(az.x, 0.0f));
+    float tny = fmaxf(fmaxf(ax.y, ay.y), fmaxf(az.y, 0.0f));
+    float tfx = fminf(fminf(bx.x, by.x), bz.x);
+    float tfy = fminf(fminf(bx.y, by.y), bz.y);
     tfx = fminf(tfx * kBestInfl, r.bestp.x);
     tfy = fminf(tfy * kBestInfl, r.bestp.y);
     px = !(tnx > tfx);

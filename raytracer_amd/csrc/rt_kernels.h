@@ -76,6 +76,7 @@ struct DevView {
     const TriCold *tri_cold;        // reference traversal order
     TreeView tree;
     int cull;                       // 0: scan every triangle (validation), 1: use the tree
+    int sorted_planes;              // 1: waves whose rays share an octant read the boxes' planes pre-ordered
     const ModelRec *models;
     const SphereRec *spheres;
     const LightRec *lights;

@@ -163,7 +163,9 @@ struct TravArgs {
     const TriRec *tris;
     const SphereRec *spheres;
     int n_tris, n_spheres;
+    int sorted_planes;               // 0: always the generic node test (RT_SORTED=0, validation)
 };
+struct P4 { uint32_t v[4]; };        // one axis' planes of a node group's four boxes (float bits)
 
 __device__ __forceinline__ void test_triangle(const TriRec *__restrict__ tris, uint32_t node,
                                               RayPair &r, uint32_t lanebits, int j, Stamps &sp)
@@ -238,6 +240,20 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
     r.bestp = r.best * kBestInfl;
     r.stop = f2{s[0], s[1]};
     r.idx = -1; r.idy = -1;
+    // Do the wave's culled rays share an octant?  (Never-culled and parked rays do not vote: both
+    // planes of an axis give them the same parameter.)
+    uint32_t oct = 8u;
+    const float inv[3][2] = {{r.ix.x, r.ix.y}, {r.iy.x, r.iy.y}, {r.iz.x, r.iz.y}};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const bool v0 = live[0] & !wild[0], v1 = live[1] & !wild[1];
+        const bool n0 = (__float_as_uint(inv[a][0]) >> 31) != 0u, n1 = (__float_as_uint(inv[a][1]) >> 31) != 0u;
+        const unsigned long long neg = __ballot(v0 & n0) | __ballot(v1 & n1);
+        const unsigned long long pos = __ballot(v0 & !n0) | __ballot(v1 & !n1);
+        if (neg && pos) oct = 0u;
+        if (neg) oct |= 1u << a;
+    }
+    r.oct = (oct & 8u) ? oct : 0u;
 }
 
 // Scene::hit for the pair in `r` (Scene.cu:8-67): on return r.best / r.idx, r.idy hold the
@@ -252,6 +268,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                                          unsigned long long *s_best, uint32_t &cost, Stamps &sp)
 {
     const TreeView &tv = A.tv;
+    const bool sorted_ok = A.sorted_planes != 0;
     RT_STAT(0, 1);
     RT_COUNT(sp, 12);
     unsigned long long pub0 = 0, pub1 = 0;       // what this wave last saw or wrote per ray
@@ -295,30 +312,36 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         uint32_t lanebits = 0;               // level 0: which (triangle, ray) pairs passed
         bool expand = true;
         const bool split = COOP && tv.top > kSplitLevel;
+        // Every culled ray of the wave in one octant (the usual case: the rays of a unit leave one
+        // point or go to one light): the node groups are read plane by plane, entry side and exit
+        // side (rt_math.h NodeGroup: lo[axis][4] at axis * 16, hi[axis][4] at 48 + axis * 16).
+        const uint32_t oct = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.oct);
+        const bool sorted = (oct & 8u) != 0u && sorted_ok;
+        // a dead box (lo = +inf, hi = -inf) shows on its x entry plane: lo.x = +inf, or hi.x = -inf
+        // for rays running towards -x; no other box has either
+        const uint32_t dead_key = 0x7f800000u | (oct & 1u) << 31;
+        uint32_t off_n[3], off_f[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const bool neg = ((oct >> a) & 1u) != 0u;
+            off_n[a] = (neg ? 48u : 0u) + 16u * (uint32_t)a;
+            off_f[a] = (neg ? 0u : 48u) + 16u * (uint32_t)a;
+        }
         for (;;) {
             if (expand) {
                 cost++;
                 RT_STAT(1, 1);
                 if (COOP) merge_in();
                 RT_MARK(sp, 7);
-                const NodeGroup G = load_uniform(&tv.groups[lane_get(lvloff, l) + g]);
-                stamp_arrived(G);
-                RT_MARK(sp, 6);
-                uint32_t key[4], lb = 0, n_pass = 0;
-#pragma unroll
-                for (int j = 0; j < kTreeArity; j++) {
-                    bool px, py;
-                    float ex, ey;
-                    node_test(r, G.lo[0][j], G.lo[1][j], G.lo[2][j], G.hi[0][j], G.hi[1][j],
-                              G.hi[2][j], px, py, ex, ey);
-                    // smallest entry parameter among this lane's passing rays
-                    float near = fminf(px ? ex : 3.0e38f, py ? ey : 3.0e38f);
-                    lb |= ((uint32_t)px << (2 * j)) | ((uint32_t)py << (2 * j + 1));
-                    // lo > hi (padding, or a triangle Model.cu:99 always rejects) is dead
-                    // for every ray, including the unculled ones
-                    unsigned long long b = __ballot(px | py);
+                const NodeGroup *gp = &tv.groups[lane_get(lvloff, l) + g];
+                uint32_t key[4], n_pass = 0, lb = 0;
+                // One child: `test` fills the two rays' verdicts and entry parameters and says
+                // whether the box is dead (lo = +inf, hi = -inf: padding, or a triangle
+                // Model.cu:99 always rejects -- dead for every ray, including the unculled ones).
+                auto child = [&](int j, bool px, bool py, float ex, float ey, bool dead) {
+                    const unsigned long long b = __ballot(px) | __ballot(py);   // the compares' own lane masks
                     key[j] = 0xffffffffu;
-                    bool take = b && !(G.lo[0][j] > G.hi[0][j]);
+                    bool take = b && !dead;
                     if (take && split && l == kSplitLevel + 1) {
                         // the subtree below this child belongs to one wave of the block
                         uint32_t node = g * kTreeArity + (uint32_t)j;
@@ -326,18 +349,54 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                     }
                     if (take) {
                         // visit order: entry parameter of the first passing lane (a coherent
-                        // wave's rays agree on it closely enough); the child index rides in
-                        // the two low mantissa bits.  ORDER = false (occlusion rays: any hit
-                        // below the threshold ends the ray, so nearest-first buys nothing):
-                        // index order.
+                        // wave's rays agree on it closely enough; the smaller of the lane's
+                        // passing rays, compared as integers: entry parameters are >= +0); the
+                        // child index rides in the two low mantissa bits.  ORDER = false
+                        // (occlusion rays: any hit below the threshold ends the ray, so
+                        // nearest-first buys nothing): index order.
                         if (ORDER) {
-                            float e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
-                                __builtin_bit_cast(int, near), __builtin_ctzll(b)));
-                            key[j] = (__builtin_bit_cast(uint32_t, e) & ~3u) | (uint32_t)j;
+                            const uint32_t ux = px ? __float_as_uint(ex) : 0x7f000000u;
+                            const uint32_t uy = py ? __float_as_uint(ey) : 0x7f000000u;
+                            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)min(ux, uy), __builtin_ctzll(b));
+                            key[j] = (e & ~3u) | (uint32_t)j;
                         } else {
                             key[j] = (uint32_t)j;
                         }
                         n_pass++;
+                    }
+                    if (l == 0)                  // leaves: which (triangle, ray) pairs passed, per lane
+                        lb |= ((uint32_t)px << (2 * j)) | ((uint32_t)py << (2 * j + 1));
+                };
+                if (sorted) {
+                    // the planes already ordered for the wave's octant: entry side, exit side
+                    const P4 nx = load_uniform((const P4 *)((const char *)gp + off_n[0]));
+                    const P4 ny = load_uniform((const P4 *)((const char *)gp + off_n[1]));
+                    const P4 nz = load_uniform((const P4 *)((const char *)gp + off_n[2]));
+                    const P4 fx = load_uniform((const P4 *)((const char *)gp + off_f[0]));
+                    const P4 fy = load_uniform((const P4 *)((const char *)gp + off_f[1]));
+                    const P4 fz = load_uniform((const P4 *)((const char *)gp + off_f[2]));
+                    stamp_arrived(fz);
+                    RT_MARK(sp, 6);
+#pragma unroll
+                    for (int j = 0; j < kTreeArity; j++) {
+                        bool px, py;
+                        float ex, ey;
+                        node_test_sorted(r, __uint_as_float(nx.v[j]), __uint_as_float(ny.v[j]), __uint_as_float(nz.v[j]),
+                                         __uint_as_float(fx.v[j]), __uint_as_float(fy.v[j]), __uint_as_float(fz.v[j]),
+                                         px, py, ex, ey);
+                        child(j, px, py, ex, ey, nx.v[j] == dead_key);
+                    }
+                } else {
+                    const NodeGroup G = load_uniform(gp);
+                    stamp_arrived(G);
+                    RT_MARK(sp, 6);
+#pragma unroll
+                    for (int j = 0; j < kTreeArity; j++) {
+                        bool px, py;
+                        float ex, ey;
+                        node_test(r, G.lo[0][j], G.lo[1][j], G.lo[2][j], G.hi[0][j], G.hi[1][j],
+                                  G.hi[2][j], px, py, ex, ey);
+                        child(j, px, py, ex, ey, __float_as_uint(G.lo[0][j]) == 0x7f800000u);
                     }
                 }
                 cswap(key[0], key[1]); cswap(key[2], key[3]);
@@ -1103,134 +1162,157 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     // the NEXT unit's ticket: drawn behind the prologue's loads, it comes back while this unit is traced
     if (lane == 0)
         ticket = atomicAdd(next_counter, 1u);
-    for (int round = 0; round < 2; round++) {
-        if (!__ballot(todo[0] | todo[1]))
-            break;
-        uint32_t ctr[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t smp = ((uint32_t)h * 64u + lane) >> px_log2;
-            ctr[h] = base_c[h] + (smp - base_s[h]) * dhat[h];
-            tmp[(5 + h) * kBlock] = base_c[h];
-            tmp[(7 + h) * kBlock] = base_s[h];
-            tmp[(9 + h) * kBlock] = dhat[h];
-        }
-        PrimaryTrace o;
-        trace_primary<CULL>(A, env, lane, pix, ctr, todo, o, cost, tmp, sp);
-        uint32_t q[2], smp[2], p[2];
-        uint32_t ln = lane;
-        asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t r = (uint32_t)h * 64u + ln;
-            q[h] = r & px_mask;
-            smp[h] = r >> px_log2;
-            p[h] = min(A.p0 + (unit << px_log2) + q[h], p_end - 1u);
-            base_c[h] = tmp[(5 + h) * kBlock];
-            base_s[h] = tmp[(7 + h) * kBlock];
-            dhat[h] = tmp[(9 + h) * kBlock];
-        }
-        const unsigned long long m0 = __ballot(todo[0] && o.delta[0] != dhat[0]);
-        const unsigned long long m1 = __ballot(todo[1] && o.delta[1] != dhat[1]);
-        uint32_t first[2], src[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            first[h] = ss;
-            for (uint32_t k = ss; k-- > 0u;) {
-                const uint32_t r = (k << px_log2) + q[h];
-                const bool bit = (((r < 64u ? m0 : m1) >> (r & 63u)) & 1ull) != 0ull;
-                first[h] = bit ? k : first[h];
-            }
-            src[h] = (min(first[h], ss - 1u) << px_log2) + q[h];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t lo = (uint32_t)__shfl((int)o.delta[0], (int)(src[h] & 63u));
-            const uint32_t hi = (uint32_t)__shfl((int)o.delta[1], (int)(src[h] & 63u));
-            const uint32_t dj = src[h] < 64u ? lo : hi;
-            if (todo[h] && smp[h] <= first[h]) {             // traced from the right counter: final
-                put_record(col0, (uint32_t)h * 64u + ln, o, h);
-                if (smp[h] + 1u == A.n_samples)
-                    write_last(A, o, h, p[h], ctr[h]);
-                todo[h] = false;
-            }
-            if (first[h] < ss) {                             // the pixel goes on from behind sample `first`
-                const bool changed = first[h] == base_s[h];
-                base_c[h] += (first[h] - base_s[h]) * dhat[h] + dj;
-                base_s[h] = first[h] + 1u;
-                dhat[h] = changed ? dj : dhat[h];
-            }
-        }
-    }
-
-    // ---------------- phase H: pixels still open after two rounds, one at a time
-    {
-        uint32_t ln = lane;
-        asm volatile("" : "+v"(ln));
-        unsigned long long open[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t r = (uint32_t)h * 64u + ln;
-            open[h] = __ballot(todo[h] && (r >> px_log2) == base_s[h]);
-            tmp[(5 + h) * kBlock] = base_c[h];               // read back below from the speaking lane's column
-            tmp[(7 + h) * kBlock] = base_s[h];
-        }
-        while (open[0] | open[1]) {
+    // Phases P and H share ONE call site of the closest-hit traversal (one copy of its loop in the
+    // instruction cache).  mode 0, 1: the two prediction rounds; mode 2: the pixels still open
+    // after them, one at a time, eight samples per pass.
+    unsigned long long stride = 0ull;                        // bits at the multiples of px: one pixel's samples in a lane mask
+    for (uint32_t i = 0; i < 64u; i += 1u << px_log2) stride |= 1ull << i;
+    int mode = 0;
+    unsigned long long open[2] = {0ull, 0ull};               // lanes that speak for an open pixel
+    uint32_t e_c = 0, e_s = A.n_samples, qq = 0, p1 = 0, pix1 = 0;   // the open pixel under enumeration (wave-uniform)
+    for (;;) {
+        if (mode < 2 && !__ballot(todo[0] | todo[1]))
+            break;                                           // every sample is final
+        if (mode == 2 && e_s >= A.n_samples) {               // on to the next open pixel
+            if (!(open[0] | open[1]))
+                break;
             const int hh = open[0] ? 0 : 1;
             const uint32_t sl = (uint32_t)__builtin_ctzll(open[hh]);
             open[hh] &= open[hh] - 1ull;
-            const uint32_t qq = ((uint32_t)hh * 64u + sl) & px_mask;
-            const uint32_t p1 = min(A.p0 + (unit << px_log2) + qq, p_end - 1u);
-            uint32_t e_c = tmp0[sl + (5 + hh) * kBlock];     // wave-uniform LDS reads
-            uint32_t e_s = tmp0[sl + (7 + hh) * kBlock];
-            e_c = (uint32_t)__builtin_amdgcn_readfirstlane(e_c);
-            e_s = (uint32_t)__builtin_amdgcn_readfirstlane(e_s);
-            const uint32_t pix1 = v.pixmap[p1];
-            for (int round = 0; round < 16 && e_s < A.n_samples; round++) {
-                const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);
-                uint32_t hpix[2] = {pix1, pix1}, ctr[2];
-                bool live[2];
+            qq = ((uint32_t)hh * 64u + sl) & px_mask;
+            p1 = min(A.p0 + (unit << px_log2) + qq, p_end - 1u);
+            // wave-uniform LDS reads of what the speaking lane parked
+            e_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmp0[sl + (5 + hh) * kBlock]);
+            e_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmp0[sl + (7 + hh) * kBlock]);
+            pix1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.pixmap[p1]);
+            if (e_s >= A.n_samples)
+                continue;
+        }
+        const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);   // mode 2: samples this pass settles
+        uint32_t tp[2], ctr[2];
+        bool live[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (mode < 2) {
+                const uint32_t smp = ((uint32_t)h * 64u + lane) >> px_log2;
+                ctr[h] = base_c[h] + (smp - base_s[h]) * dhat[h];
+                tmp[(5 + h) * kBlock] = base_c[h];
+                tmp[(7 + h) * kBlock] = base_s[h];
+                tmp[(9 + h) * kBlock] = dhat[h];
+                tp[h] = pix[h];
+                live[h] = todo[h];
+            } else {
+                // candidate r of the table: k samples before it, b hits without and c hits with
+                // a usable BRDF sample among them
+                uint32_t k, a, b, c;
+                hard_candidate((uint32_t)h * 64u + lane, k, a, b, c);
+                live[h] = k < e_n;
+                ctr[h] = e_c + 2u * a + (2u + L) * b + (3u + L) * c;
+                tp[h] = pix1;
+            }
+        }
+        // rows 5-8 of every lane's column (the pixels' bookkeeping) survive this: trace_primary parks in rows 0-4
+        PrimaryTrace o;
+        trace_primary<CULL>(A, env, lane, tp, ctr, live, o, cost, tmp, sp);
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
+        if (mode < 2) {
+            uint32_t q[2], smp[2], p[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t r = (uint32_t)h * 64u + ln;
+                q[h] = r & px_mask;
+                smp[h] = r >> px_log2;
+                p[h] = min(A.p0 + (unit << px_log2) + q[h], p_end - 1u);
+                pix[h] = tp[h];
+                todo[h] = live[h];
+                base_c[h] = tmp[(5 + h) * kBlock];
+                base_s[h] = tmp[(7 + h) * kBlock];
+                dhat[h] = tmp[(9 + h) * kBlock];
+            }
+            // first sample of each pixel whose draw count is not the expected one
+            const unsigned long long m0 = __ballot(todo[0] && o.delta[0] != dhat[0]);
+            const unsigned long long m1 = __ballot(todo[1] && o.delta[1] != dhat[1]);
+            uint32_t first[2], src[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                first[h] = ss;
+                if (px_log2 < 6u) {                          // sample k of pixel q sits at bit (k << px_log2) + q
+                    const unsigned long long w0 = (m0 >> q[h]) & stride, w1 = (m1 >> q[h]) & stride;
+                    if (w0)      first[h] = (uint32_t)__builtin_ctzll(w0) >> px_log2;
+                    else if (w1) first[h] = (64u + (uint32_t)__builtin_ctzll(w1)) >> px_log2;
+                } else {
+                    for (uint32_t k = ss; k-- > 0u;) {       // at most two samples per pixel
+                        const uint32_t r = (k << px_log2) + q[h];
+                        const bool bit = (((r < 64u ? m0 : m1) >> (r & 63u)) & 1ull) != 0ull;
+                        first[h] = bit ? k : first[h];
+                    }
+                }
+                src[h] = (min(first[h], ss - 1u) << px_log2) + q[h];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                // its draw count, from the lane that holds it
+                const uint32_t lo = (uint32_t)__shfl((int)o.delta[0], (int)(src[h] & 63u));
+                const uint32_t hi = (uint32_t)__shfl((int)o.delta[1], (int)(src[h] & 63u));
+                const uint32_t dj = src[h] < 64u ? lo : hi;
+                if (todo[h] && smp[h] <= first[h]) {         // traced from the right counter: final
+                    put_record(col0, (uint32_t)h * 64u + ln, o, h);
+                    if (smp[h] + 1u == A.n_samples)
+                        write_last(A, o, h, p[h], ctr[h]);
+                    todo[h] = false;
+                }
+                if (first[h] < ss) {                         // the pixel goes on from behind sample `first`
+                    // ... expecting what it expected before, unless its very first open sample
+                    // was the odd one (then the pixel as a whole has changed: expect that instead)
+                    const bool changed = first[h] == base_s[h];
+                    base_c[h] += (first[h] - base_s[h]) * dhat[h] + dj;
+                    base_s[h] = first[h] + 1u;
+                    dhat[h] = changed ? dj : dhat[h];
+                }
+            }
+            if (mode == 1) {
+                // Pixels still open flip between outcomes from sample to sample.  The lane of a
+                // pixel's first open sample speaks for it; its counter and sample index go to
+                // LDS, where the enumeration reads them (wave-uniform).
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    uint32_t k, a, b, c;
-                    hard_candidate((uint32_t)h * 64u + lane, k, a, b, c);
-                    live[h] = k < e_n;
-                    ctr[h] = e_c + 2u * a + (2u + L) * b + (3u + L) * c;
+                    open[h] = __ballot(todo[h] && smp[h] == base_s[h]);
+                    tmp[(5 + h) * kBlock] = base_c[h];
+                    tmp[(7 + h) * kBlock] = base_s[h];
                 }
-                // the unit's open-pixel bookkeeping sits in rows 5-8 of every lane's column and
-                // must survive this traversal: trace_primary parks only in rows 0-4
-                PrimaryTrace o;
-                trace_primary<CULL>(A, env, lane, hpix, ctr, live, o, cost, tmp, sp);
-                const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
-                const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
-                const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
-                const unsigned long long b1 = __ballot(live[1] && o.delta[1] == 2u + L);
-                unsigned long long c0 = 0ull, c1 = 0ull;     // walk the chain through the table (wave-uniform)
-                uint32_t b = 0, c = 0, c_new = e_c;
-                for (uint32_t k = 0; k < e_n; k++) {
-                    const uint32_t t = b + c;
-                    const uint32_t r = hard_level_off(k) + t * (t + 1u) / 2u + c;
-                    const unsigned long long bit = 1ull << (r & 63u);
-                    if (r < 64u) c0 |= bit; else c1 |= bit;
-                    if (((r < 64u ? u0 : u1) & bit) != 0ull)      { c_new += 3u + L; c++; }
-                    else if (((r < 64u ? b0 : b1) & bit) != 0ull) { c_new += 2u + L; b++; }
-                    else                                          { c_new += 2u; }
-                }
-                uint32_t l2 = lane;
-                asm volatile("" : "+v"(l2));
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                    if ((((h ? c1 : c0) >> l2) & 1ull) != 0ull) {
-                        uint32_t k, ca, cb, cc;
-                        hard_candidate((uint32_t)h * 64u + l2, k, ca, cb, cc);
-                        const uint32_t s = e_s + k;
-                        put_record(col0, (s << px_log2) + qq, o, h);
-                        if (s + 1u == A.n_samples)
-                            write_last(A, o, h, p1, ctr[h]);
-                    }
-                e_s += e_n;
-                e_c = c_new;
+                e_s = A.n_samples;                           // nothing under enumeration yet
             }
+            mode++;
+        } else {
+            // which candidates lie on the chain: walk it through the table (wave-uniform)
+            const unsigned long long u0 = __ballot(live[0] && o.delta[0] == 3u + L);
+            const unsigned long long u1 = __ballot(live[1] && o.delta[1] == 3u + L);
+            const unsigned long long b0 = __ballot(live[0] && o.delta[0] == 2u + L);
+            const unsigned long long b1 = __ballot(live[1] && o.delta[1] == 2u + L);
+            unsigned long long c0 = 0ull, c1 = 0ull;
+            uint32_t b = 0, c = 0, c_new = e_c;
+            for (uint32_t k = 0; k < e_n; k++) {
+                const uint32_t t = b + c;
+                const uint32_t r = hard_level_off(k) + t * (t + 1u) / 2u + c;
+                const unsigned long long bit = 1ull << (r & 63u);
+                if (r < 64u) c0 |= bit; else c1 |= bit;
+                if (((r < 64u ? u0 : u1) & bit) != 0ull)      { c_new += 3u + L; c++; }
+                else if (((r < 64u ? b0 : b1) & bit) != 0ull) { c_new += 2u + L; b++; }
+                else                                          { c_new += 2u; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if ((((h ? c1 : c0) >> ln) & 1ull) != 0ull) {
+                    uint32_t k, ca, cb, cc;
+                    hard_candidate((uint32_t)h * 64u + ln, k, ca, cb, cc);
+                    const uint32_t smp = e_s + k;
+                    put_record(col0, (smp << px_log2) + qq, o, h);   // into the column of the lane that owns the sample
+                    if (smp + 1u == A.n_samples)
+                        write_last(A, o, h, p1, ctr[h]);
+                }
+            e_s += e_n;
+            e_c = c_new;
         }
     }
     // every record of the unit is final and in LDS; lanes read their own column from here on
@@ -1605,6 +1687,7 @@ static TravArgs trav_args(const DevView &v)
     TravArgs T{};
     T.tv = v.tree; T.tris = v.tris; T.spheres = v.spheres;
     T.n_tris = v.n_tris; T.n_spheres = v.n_spheres;
+    T.sorted_planes = v.sorted_planes;
     return T;
 }
 

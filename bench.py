@@ -49,8 +49,9 @@ SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
 RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out per ray
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
-VALU_CYCLES = 2.0            # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md,
-                             # per-instruction constants; measured here too: C5's shadow rays retire one per 2.15 cycles per SIMD, profiles/r02_c5_*)
+VALU_CYCLES = 4.0            # issue slots a wave64 VALU instruction of this mix takes on its SIMD: with four waves
+                             # per SIMD each busy 24.8 % of its cycles executing VALU (C5, SQ_ACTIVE_INST_VALU over
+                             # SQ_WAVE_CYCLES) the SIMD retires one instruction per 4.3 cycles and no faster
 BATCH_PIXEL_BYTES = 60.0     # k_batch, per pixel and launch: fb 16+16, rng counter 4+4, last draws 4+4, pixmap 4, id + t 8
 PROFILE_ROUNDS = ("r02", "r01")   # committed rocprofv3 summaries under profiles/, newest first
 

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rt_device.h"
 
@@ -990,6 +991,31 @@ struct BatchArgs {
 // What a lane carries across a traversal is parked in LDS (slot i of a lane: st[i * kBlock]),
 // as in the path kernel: the closest-hit traversal needs the register file to itself, and what
 // the compiler would otherwise spill goes to scratch memory and from there to HBM.
+// Is the BRDF sample of PathTracer.cu:76 usable, i.e. !(pdf < 0.0001f || length(f) < 0.0001f) (:77)?
+// At depth 0 nothing else of rec_sample_f is read.  For a Lambertian surface pdf = wl.y / pi with
+// wl.y = sqrt(max(0, 1 - dx^2 - dy^2)), (dx, dy) = r (sin, cos)(theta) (sampleHemi, material.cu:28-50), and
+// f = colour / pi if wo.y > 0 and wl.y > 0, else 0.  While r^2 < 0.9999 the sample lies well inside
+// the unit disk -- wl.y > 0.0099, pdf > 0.003 whatever the last bits of sin / cos are -- so the verdict
+// is that of `wo.y > 0 && |colour / pi| >= 0.0001`; only samples on the rim (5e-5 of them) need
+// sampleHemi's own arithmetic, double-precision sin / cos included.  Same verdict either way.
+__device__ __forceinline__ bool brdf_sample_usable(const Hit &H, const ModelRec &M, float wo_y, float sx, float sy)
+{
+    if (M.mat_type == kMatLambertian) {
+        const float rx = 2.0f * sx - 1.0f, ry = 2.0f * sy - 1.0f;
+        const float r = fabsf(rx) > fabsf(ry) ? rx : ry;
+        if (r * r < 0.9999f && !(rx == 0.0f && ry == 0.0f)) {
+            v3 c = H.color;
+            if (c.x < 0.0f)
+                c = mk3(M.color[0], M.color[1], M.color[2]);
+            return wo_y > 0.0f && !(length(scale(c, kInvPi)) < 0.0001f);
+        }
+    }
+    v3 wi;
+    float pdf;
+    v3 f = rec_sample_f_y(H, M, wo_y, wi, pdf, sx, sy);
+    return !(pdf < 0.0001f || length(f) < 0.0001f);
+}
+
 constexpr int kPrimSlots = 12;       // 0-1 pixel, 2-3 counter, 4 live bits; 5-10 the caller's
 struct PrimaryTrace {
     uint32_t delta[2];               // draws the sample consumes
@@ -1056,10 +1082,7 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
             // PathTracer.cu:76-77: only whether the BRDF sample is usable matters at depth 0
             float u[4];
             pixel_uniform4(pix[h], ctr[h] + 1u, u);
-            v3 wi;
-            float pdf;
-            v3 f = rec_sample_f_y(H, v.models[H.model], wo_y, wi, pdf, u[0], u[1]);
-            if (!(pdf < 0.0001f || length(f) < 0.0001f))
+            if (brdf_sample_usable(H, v.models[H.model], wo_y, u[0], u[1]))
                 o.delta[h] += 1u;                            // the next iteration's draw (:27) before its break (:64)
             o.rec[h][0] = H.pos.x; o.rec[h][1] = H.pos.y; o.rec[h][2] = H.pos.z;
             o.rec[h][3] = H.normal.x; o.rec[h][4] = H.normal.y; o.rec[h][5] = H.normal.z;
@@ -1323,14 +1346,16 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
     const uint32_t own_pl = A.p0 + (unit << px_log2) + ln;
-    const bool owner = ln <= px_mask && own_pl < p_end;     // px == 128: both halves, below
-    // the framebuffer texels: requested now, used after the shadow rays
+    // the framebuffer texels: requested now, used after the shadow rays (who reads what: the epilogue below)
     float4 prev0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), prev1 = prev0;
-    if (px_log2 == 7u) {
-        if (own_pl < p_end) prev0 = v.fb[own_pl];
-        if (own_pl + 64u < p_end) prev1 = v.fb[own_pl + 64u];
-    } else if (owner) {
-        prev0 = v.fb[own_pl];
+    float prevc = 0.0f;
+    if (px_log2 >= 5u) {
+        if (ln <= px_mask && own_pl < p_end) prev0 = v.fb[own_pl];
+        if (px_log2 == 7u && own_pl + 64u < p_end) prev1 = v.fb[own_pl + 64u];
+    } else {
+        const uint32_t q = ln & px_mask, ch = ln >> px_log2;
+        const uint32_t pl = A.p0 + (unit << px_log2) + q;
+        if (ch < 3u && pl < p_end) prevc = ((const float *)&v.fb[pl])[ch];
     }
     struct RS { v3 pos, normal; float wo_y; int model; v3 le, contrib; float thr; } S[2];
     bool hit[2], cast[2] = {false, false};
@@ -1434,8 +1459,9 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
     }
     RT_MARK(sp, 3);
-    // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64).  The radiance of every
-    // sample goes to LDS with the sample's weights 1 / cnt and (1 / cnt)(cnt - 1) (kernel.cu:65-66).
+    // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64).  Every sample's share of the
+    // running mean px = frac2 * prev + frac1 * c (kernel.cu:65-66,75) goes to LDS: its term
+    // frac1 * c, which does not depend on the samples before it, and its frac2.
     float *const ft = (float *)tmp;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1443,41 +1469,51 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         const uint32_t smp = ((uint32_t)h * 64u + ln) >> px_log2;
         const int cnt = A.cnt0 + (int)smp + 1;
         const float frac1 = 1.0f / cnt, frac2 = frac1 * (cnt - 1);
-        ft[(5 * h + 0) * kBlock] = res.x; ft[(5 * h + 1) * kBlock] = res.y; ft[(5 * h + 2) * kBlock] = res.z;
-        ft[(5 * h + 3) * kBlock] = frac1; ft[(5 * h + 4) * kBlock] = frac2;
+        ft[(4 * h + 0) * kBlock] = frac1 * res.x; ft[(4 * h + 1) * kBlock] = frac1 * res.y;
+        ft[(4 * h + 2) * kBlock] = frac1 * res.z; ft[(4 * h + 3) * kBlock] = frac2;
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-    if (px_log2 == 7u) {                                     // one sample: both pixels of a lane, no exchange
-        if (A.n_samples) {
+    if (px_log2 >= 5u) {
+        // few samples per pixel (batches of up to 4): lane q owns pixel q (and q + 64), all channels
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t pl = own_pl + (uint32_t)h * 64u;
-                if (pl < p_end) {
-                    float4 prev = h ? prev1 : prev0;
-                    const float frac1 = ft[(5 * h + 3) * kBlock], frac2 = ft[(5 * h + 4) * kBlock];
-                    prev.x = frac2 * prev.x + frac1 * ft[(5 * h + 0) * kBlock];
-                    prev.y = frac2 * prev.y + frac1 * ft[(5 * h + 1) * kBlock];
-                    prev.z = frac2 * prev.z + frac1 * ft[(5 * h + 2) * kBlock];
+        for (int h = 0; h < 2; h++) {
+            const uint32_t q = (uint32_t)h * 64u + ln;       // second pass only when a wave holds 128 pixels
+            const uint32_t pl = A.p0 + (unit << px_log2) + q;
+            if (q <= px_mask && pl < p_end) {
+                const float *const f0 = (const float *)tmp0;
+                float4 prev = h ? prev1 : prev0;
+                for (uint32_t smp = 0; smp < A.n_samples; smp++) {
+                    const uint32_t r = (smp << px_log2) + q;
+                    const float *c = f0 + (r & 63u) + (r >> 6) * (4u * kBlock);
+                    const float frac2 = c[3 * kBlock];
+                    prev.x = frac2 * prev.x + c[0];
+                    prev.y = frac2 * prev.y + c[kBlock];
+                    prev.z = frac2 * prev.z + c[2 * kBlock];
                     prev.w = 1.0f;
-                    v.fb[pl] = prev;
                 }
+                v.fb[pl] = prev;
             }
         }
-    } else if (owner) {
-        // lane q < px owns pixel q: its samples in order, each from the column of the lane that traced it
-        const float *const f0 = (const float *)tmp0;
-        float4 prev = prev0;
-        for (uint32_t smp = 0; smp < A.n_samples; smp++) {
-            const uint32_t r = (smp << px_log2) + ln;
-            const float *c = f0 + (r & 63u) + (r >> 6) * (5u * kBlock);
-            const float frac1 = c[3 * kBlock], frac2 = c[4 * kBlock];
-            prev.x = frac2 * prev.x + frac1 * c[0];
-            prev.y = frac2 * prev.y + frac1 * c[kBlock];
-            prev.z = frac2 * prev.z + frac1 * c[2 * kBlock];
-            prev.w = 1.0f;
+    } else {
+        // lane ch * px + q runs channel ch of pixel q through the pixel's samples, in order, each
+        // from the column of the lane that traced it
+        const uint32_t q = ln & px_mask, ch = ln >> px_log2;
+        const uint32_t pl = A.p0 + (unit << px_log2) + q;
+        if (ch < 3u && pl < p_end) {
+            const float *c = (const float *)tmp0 + q + ch * kBlock;
+            float prev = prevc;
+            const uint32_t half = min(A.n_samples, 64u >> px_log2);          // samples held by lanes' first rays
+            for (uint32_t smp = 0; smp < half; smp++, c += 1u << px_log2)
+                prev = c[(3u - ch) * kBlock] * prev + c[0];
+            c = (const float *)tmp0 + q + (4u + ch) * kBlock;
+            for (uint32_t smp = half; smp < A.n_samples; smp++, c += 1u << px_log2)
+                prev = c[(3u - ch) * kBlock] * prev + c[0];
+            float *texel = (float *)&v.fb[pl];
+            texel[ch] = prev;
+            if (ch == 0u)
+                texel[3] = 1.0f;
         }
-        v.fb[own_pl] = prev;
     }
     if (lane == 0 && n_shadow)
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);

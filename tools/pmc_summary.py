@@ -17,9 +17,12 @@ def main():
     for want in sys.argv[1].split(","):
         tot = collections.defaultdict(float)
         disp = collections.defaultdict(set)
+        source = {}                      # a counter collected in several passes is taken from the first
         for path in sys.argv[2:]:
             for r in csv.DictReader(open(path)):
                 if want != short_name(r["Kernel_Name"]):
+                    continue
+                if source.setdefault(r["Counter_Name"], path) != path:
                     continue
                 tot[r["Counter_Name"]] += float(r["Counter_Value"])
                 disp[r["Counter_Name"]].add(r["Dispatch_Id"])

@@ -36,7 +36,7 @@ for c in $CONFIGS; do
     timeout -s KILL 300 rocprofv3 --pmc $ctrs --output-format csv -d $O/$name -o $c -- python3 bench.py $A > $O/${name}_$c.log 2>&1
   done
   python3 tools/pmc_traffic.py $c $O/fetch/${c}_counter_collection.csv $O/write/${c}_counter_collection.csv $O/traffic.json > $O/traffic_$c.txt
-  python3 tools/pmc_summary.py k_shadow,k_primary,k_primary_hard,k_path,k_fused $O/sq1/${c}_counter_collection.csv $O/sq2/${c}_counter_collection.csv $O/sq3/${c}_counter_collection.csv $O/sqc/${c}_counter_collection.csv $O/l2/${c}_counter_collection.csv > $O/sq_$c.txt
+  python3 tools/pmc_summary.py k_batch,k_path,k_intersect,k_fill_i32,k_scatter_image $O/sq1/${c}_counter_collection.csv $O/sq2/${c}_counter_collection.csv $O/sq3/${c}_counter_collection.csv $O/sqc/${c}_counter_collection.csv $O/l2/${c}_counter_collection.csv > $O/sq_$c.txt
   cp $O/kt/${c}_kernel_stats.csv $O/kernel_stats_$c.csv 2>/dev/null || true
   # the raw per-dispatch CSVs are large: keep the summaries only
   rm -rf $O/fetch/${c}_* $O/write/${c}_* $O/l2/${c}_* $O/sq1/${c}_* $O/sq2/${c}_* $O/sq3/${c}_* $O/sqc/${c}_* $O/kt/${c}_*

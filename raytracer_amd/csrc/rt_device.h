@@ -155,10 +155,13 @@ constexpr float kEpsDefl = kEps * 0.999999f;
 // 1 / d for the slab test.  A component below 1e-30 in magnitude is replaced by +-1e-30:
 // over the t range of the path (t < 1e6) that moves the ray by less than 1e-24, far
 // inside the slack the boxes carry.
+// The hardware reciprocal (1 ulp) is enough: both planes of an axis and the ray's origin are scaled by
+// the same value, so a box's interval only stretches by 1 +- 2^-23 as a whole, and its comparison with
+// the closest hit so far carries the factor kBestInfl = 1 + 4e-6.
 __device__ __forceinline__ float slab_inv(float d)
 {
     float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;
-    return 1.0f / a;
+    return __builtin_amdgcn_rcpf(a);
 }
 
 // Conservative slab test of one box against both rays: true = some triangle below the
@@ -492,6 +495,13 @@ __device__ __forceinline__ v3 rec_sample_f_y(const Hit &h, const ModelRec &M, fl
     return res;
 }
 
-__device__ __forceinline__ bool is_black(v3 x) { return length(x) < 0.001f; }   // Scene.cu:3-5
+// black(x) = length(x) < 0.001f (Scene.cu:3-5) and the `length(f) < 0.0001f` of PathTracer.cu:77, without the
+// square root: sqrtf is correctly rounded and monotone, so sqrtf(y) < c holds exactly for the y below
+// the smallest float whose root reaches c -- 0x1.0c6f7ap-20 for c = 0.001f, 0x1.5798ecp-27 for
+// c = 0.0001f (found by bisection over the float bit patterns; tests/test_oracle_cpu.py checks both).
+constexpr float kLenSqBelow1e3 = 0x1.0c6f7ap-20f;
+constexpr float kLenSqBelow1e4 = 0x1.5798ecp-27f;
+__device__ __forceinline__ bool is_black(v3 x) { return dot(x, x) < kLenSqBelow1e3; }
+__device__ __forceinline__ bool len_below_1e4(v3 x) { return dot(x, x) < kLenSqBelow1e4; }
 
 } // namespace rt

@@ -780,7 +780,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
             v3 wi;
             float pdf;
             v3 f = rec_sample_f_y(H, M, S[h].wo_y, wi, pdf, u[0], u[1]);   // PathTracer.cu:76
-            bool done = (pdf < 0.0001f || length(f) < 0.0001f);          // PathTracer.cu:77
+            bool done = (pdf < 0.0001f || len_below_1e4(f));             // PathTracer.cu:77
             if (!done) {
                 S[h].beta = mul(S[h].beta, divs(scale(f, fabsf(dot(wi, H.normal))), pdf));   // :79
                 Ray nr = spawn_ray(H, wi);                               // :80
@@ -1007,13 +1007,13 @@ __device__ __forceinline__ bool brdf_sample_usable(const Hit &H, const ModelRec 
             v3 c = H.color;
             if (c.x < 0.0f)
                 c = mk3(M.color[0], M.color[1], M.color[2]);
-            return wo_y > 0.0f && !(length(scale(c, kInvPi)) < 0.0001f);
+            return wo_y > 0.0f && !len_below_1e4(scale(c, kInvPi));
         }
     }
     v3 wi;
     float pdf;
     v3 f = rec_sample_f_y(H, M, wo_y, wi, pdf, sx, sy);
-    return !(pdf < 0.0001f || length(f) < 0.0001f);
+    return !(pdf < 0.0001f || len_below_1e4(f));
 }
 
 constexpr int kPrimSlots = 12;       // 0-1 pixel, 2-3 counter, 4 live bits; 5-10 the caller's
@@ -1346,16 +1346,15 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
     const uint32_t own_pl = A.p0 + (unit << px_log2) + ln;
-    // the framebuffer texels: requested now, used after the shadow rays (who reads what: the epilogue below)
-    float4 prev0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), prev1 = prev0;
-    float prevc = 0.0f;
+    // the framebuffer texels: requested now, used after the shadow rays (who reads what: the epilogue
+    // below; one register set for all unit shapes, .x alone in the channel-parallel form)
+    float4 prev0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (px_log2 >= 5u) {
         if (ln <= px_mask && own_pl < p_end) prev0 = v.fb[own_pl];
-        if (px_log2 == 7u && own_pl + 64u < p_end) prev1 = v.fb[own_pl + 64u];
     } else {
         const uint32_t q = ln & px_mask, ch = ln >> px_log2;
         const uint32_t pl = A.p0 + (unit << px_log2) + q;
-        if (ch < 3u && pl < p_end) prevc = ((const float *)&v.fb[pl])[ch];
+        if (ch < 3u && pl < p_end) prev0.x = ((const float *)&v.fb[pl])[ch];
     }
     struct RS { v3 pos, normal; float wo_y; int model; v3 le, contrib; float thr; } S[2];
     bool hit[2], cast[2] = {false, false};
@@ -1450,9 +1449,19 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
                 Ray sr;
                 sr.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
                 sr.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
-                v3 hp = sid < v.n_tris ? ray_pos(sr, best)
-                                       : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
-                blocked = length(sub(hp, sr.o)) < S[h].thr;
+                // occlusion form: a hit safely below the threshold blocks (the margin the ray was
+                // cast with covers the difference between t and |fl(o + t d) - o|); only inside the
+                // band does the reference's own comparison decide
+                const float m = 1e-4f * (fabsf(S[h].thr) + fabsf(sr.o.x) + fabsf(sr.o.y) + fabsf(sr.o.z)) + 1e-6f;
+                const bool sure = A.occlusion && best < S[h].thr - m;
+                blocked = sure;
+                if (__ballot(!sure)) {
+                    if (!sure) {
+                        v3 hp = sid < v.n_tris ? ray_pos(sr, best)
+                                               : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
+                        blocked = length(sub(hp, sr.o)) < S[h].thr;
+                    }
+                }
             }
             if (!blocked)                                    // res += ... in light order (Scene.cu:120)
                 S[h].le = add(S[h].le, S[h].contrib);
@@ -1482,7 +1491,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             const uint32_t pl = A.p0 + (unit << px_log2) + q;
             if (q <= px_mask && pl < p_end) {
                 const float *const f0 = (const float *)tmp0;
-                float4 prev = h ? prev1 : prev0;
+                float4 prev = h ? v.fb[pl] : prev0;           // (a wave of 128 pixels: the second texel only now)
                 for (uint32_t smp = 0; smp < A.n_samples; smp++) {
                     const uint32_t r = (smp << px_log2) + q;
                     const float *c = f0 + (r & 63u) + (r >> 6) * (4u * kBlock);
@@ -1502,7 +1511,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         const uint32_t pl = A.p0 + (unit << px_log2) + q;
         if (ch < 3u && pl < p_end) {
             const float *c = (const float *)tmp0 + q + ch * kBlock;
-            float prev = prevc;
+            float prev = prev0.x;
             const uint32_t half = min(A.n_samples, 64u >> px_log2);          // samples held by lanes' first rays
             for (uint32_t smp = 0; smp < half; smp++, c += 1u << px_log2)
                 prev = c[(3u - ch) * kBlock] * prev + c[0];

@@ -158,3 +158,16 @@ def test_directional_light_closed_form():
                                    np.float32([0.0, 200.0, 0.0]), np.float32([0.0, -1.98, -1.0]), 0)
     # that ray lands at (0, 2, -100), straight below the blocker's interior: blocked
     assert prim2 == 0 and (rgb2 == 0).all()
+
+
+def test_squared_length_thresholds():
+    """The HIP path decides `length(x) < 0.001f` (Scene.cu:3-5) and `length(f) < 0.0001f`
+    (PathTracer.cu:77) on the squared length (rt_device.h kLenSqBelow1e3 / 1e4): with a correctly
+    rounded square root, sqrtf(y) < c exactly for the floats y below the thresholds."""
+    for c, thr in ((np.float32(0.001), float.fromhex("0x1.0c6f7ap-20")), (np.float32(0.0001), float.fromhex("0x1.5798ecp-27"))):
+        t = np.float32(thr)
+        assert float(t) == thr                                        # representable
+        below = np.nextafter(t, np.float32(0.0))
+        assert np.sqrt(below, dtype=np.float32) < c and not (np.sqrt(t, dtype=np.float32) < c)
+        y = np.linspace(0.0, 4.0 * thr, 200001).astype(np.float32)
+        assert np.array_equal(np.sqrt(y, dtype=np.float32) < c, y < t)

@@ -17,6 +17,7 @@
 #include "rt_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -119,8 +120,27 @@ extern "C" void rt_debug_stamps(unsigned long long *out, int reset)
 }
 struct Stamps {
     unsigned long long a[13];
-    unsigned long long last;
-    __device__ __forceinline__ void start() { for (int i = 0; i < 13; i++) a[i] = 0; last = __builtin_amdgcn_s_memtime(); }
+    unsigned long long last, unit_t0, unit_max, hard_units, hard_passes;
+    __device__ __forceinline__ void start()
+    {
+        for (int i = 0; i < 13; i++) a[i] = 0;
+        unit_max = hard_units = hard_passes = 0;
+        last = unit_t0 = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void unit_begin() { unit_t0 = __builtin_amdgcn_s_memtime(); }
+    // the longest unit of this wave: cycles in the high word, (expansions + triangle records) << 20 | unit below
+    __device__ __forceinline__ void unit_end(uint32_t unit, uint32_t cost)
+    {
+        const unsigned long long d = __builtin_amdgcn_s_memtime() - unit_t0;
+        const unsigned long long key = (d << 32) | ((unsigned long long)(cost > 4095u ? 4095u : cost) << 20) | (unit & 0xfffffu);
+        unit_max = key > unit_max ? key : unit_max;
+        // histogram of unit costs by power of two, and the cycles spent in each class: g_stamps[3][b], g_stamps[2+...]
+        if ((threadIdx.x & 63u) == 0) {
+            const int b = cost ? 32 - __builtin_clz(cost) : 0;
+            atomicAdd(&g_stamps[3][b > 15 ? 15 : b], 1ull);
+            atomicAdd(&g_stamps[0][b > 15 ? 15 : b], d);         // (row 0 is free: k_primary is gone)
+        }
+    }
     // close the segment that began at the previous mark and charge it to `seg`
     __device__ __forceinline__ void mark(int seg)
     {
@@ -130,13 +150,18 @@ struct Stamps {
     }
     __device__ __forceinline__ void flush(int kernel)
     {
-        if ((threadIdx.x & 63u) == 0)
+        if ((threadIdx.x & 63u) == 0) {
             for (int i = 0; i < 13; i++)
                 if (a[i]) atomicAdd(&g_stamps[kernel][i], a[i]);
+            atomicMax(&g_stamps[kernel][13], unit_max);          // the longest single unit of any wave
+            atomicAdd(&g_stamps[kernel][14], hard_units);
+            atomicAdd(&g_stamps[kernel][15], hard_passes);
+        }
     }
 };
 #define RT_MARK(sp, seg) (sp).mark(seg)
 #define RT_COUNT(sp, seg) ((sp).a[seg]++)
+#define RT_STAMP(x) x
 template <class T> __device__ __forceinline__ void stamp_arrived(const T &v)
 {
     // the load must have landed before the stamp that follows: use its first and last dword
@@ -147,6 +172,7 @@ template <class T> __device__ __forceinline__ void stamp_arrived(const T &v)
 struct Stamps { };
 #define RT_MARK(sp, seg) do { } while (0)
 #define RT_COUNT(sp, seg) do { } while (0)
+#define RT_STAMP(x)
 template <class T> __device__ __forceinline__ void stamp_arrived(const T &) { }
 #endif
 
@@ -1165,6 +1191,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     uint32_t cost = 0;
     RT_MARK(sp, 1);
     RT_COUNT(sp, 11);
+    RT_STAMP(sp.unit_begin());
 
     // ---------------- phase P: the camera rays' closest hits, records to LDS
     uint32_t pix[2], base_c[2], base_s[2], dhat[2];
@@ -1185,6 +1212,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     // the NEXT unit's ticket: drawn behind the prologue's loads, it comes back while this unit is traced
     if (lane == 0)
         ticket = atomicAdd(next_counter, 1u);
+
     // Phases P and H share ONE call site of the closest-hit traversal (one copy of its loop in the
     // instruction cache).  mode 0, 1: the two prediction rounds; mode 2: the pixels still open
     // after them, one at a time, eight samples per pass.
@@ -1208,9 +1236,11 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             e_c = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmp0[sl + (5 + hh) * kBlock]);
             e_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)tmp0[sl + (7 + hh) * kBlock]);
             pix1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v.pixmap[p1]);
+            RT_STAMP(sp.hard_units++);
             if (e_s >= A.n_samples)
                 continue;
         }
+        RT_STAMP(if (mode == 2) sp.hard_passes++);
         const uint32_t e_n = min(A.n_samples - e_s, kHardLevels);   // mode 2: samples this pass settles
         uint32_t tp[2], ctr[2];
         bool live[2];
@@ -1530,6 +1560,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     RT_MARK(sp, 10);
+    RT_STAMP(sp.unit_end(unit, cost));
 }
 
 // One kernel per batch and pixel range.  The grid is what is resident at once; waves draw units
@@ -1790,13 +1821,15 @@ static uint32_t batch_ss_log2(uint32_t n_samples)
     return l;
 }
 
-// Blocks of a launch over `units` wave-sized units: at least 24 units per wave.  A small launch
-// (a 1/8 partition) ends with its costliest units, and those finish sooner when fewer waves
-// share a SIMD with them (measured on a 1/8 partition of C3, ms per sample: 4 waves per SIMD
-// 0.083, 2 to 3 waves 0.077; C4, whose launches are four times larger, wants all four).
+// Blocks of a launch over `units` wave-sized units: at least kUnitsPerBlock / 4 units per wave, at
+// most the resident capacity.  (RT_UNITS_PER_BLOCK overrides, for tuning.)
 static uint32_t batch_grid(uint32_t units, uint32_t cap)
 {
-    return std::min<uint32_t>(std::max<uint32_t>(units / 96u, 1u), cap);
+    static const uint32_t per_block = [] {
+        const char *e = std::getenv("RT_UNITS_PER_BLOCK");
+        return (uint32_t)std::max(1, e ? std::atoi(e) : 96);
+    }();
+    return std::min<uint32_t>(std::max<uint32_t>(units / per_block, 1u), cap);
 }
 
 static BatchArgs batch_args(const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples, int cnt0, Ctl *ctl)

@@ -24,16 +24,27 @@ def main():
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else min(cfg.spp, 64)
     L = abi.lib()
     L.rt_debug_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    world = int(os.environ.get("STAMPS_WORLD", "1"))
     with abi.Context(cfg.width, cfg.height, 0) as ctx:
         ctx.upload_scene(cfg.scene)
         ctx.set_camera(cfg.camera)
+        ctx.set_partition(0, world, 64)
         ctx.render(spp, 0)
         ctx.reset()
         L.rt_debug_stamps(None, 1)
         ctx.render(spp, 0)
         out = (C.c_uint64 * 64)()
         L.rt_debug_stamps(out, 0)
-    for k, kname in enumerate(["k_primary", "k_shadow", "k_batch", "-"]):
+    hist = [int(out[48 + i]) for i in range(16)]
+    cyc = [int(out[i]) for i in range(16)]
+    if sum(hist):
+        print("unit cost (node groups + triangle records) -> units, share of all unit cycles, mean cycles")
+        for b in range(16):
+            if hist[b]:
+                lo = 0 if b == 0 else 1 << (b - 1)
+                print(f"  {lo:6d}..{(1 << b) - 1:6d}: {hist[b]:9d} units  {100.0 * cyc[b] / max(sum(cyc), 1):6.2f} % of cycles  "
+                      f"{cyc[b] / hist[b]:10.0f} cycles each")
+    for k, kname in enumerate(["-", "-", "k_batch", "-"]):
         a = [int(out[16 * k + i]) for i in range(16)]
         if not a[0]:
             continue
@@ -43,6 +54,9 @@ def main():
             if a[i]:
                 print(f"  {SEG[i]:32s} {100.0 * a[i] / a[0]:6.2f} %   {a[i] / max(a[11], 1):10.0f} cycles / unit")
         print(f"  {'unaccounted':32s} {100.0 * (a[0] - sum(a[1:11])) / a[0]:6.2f} %")
+        cyc, cost, unit = a[13] >> 32, (a[13] >> 20) & 0xfff, a[13] & 0xfffff
+        print(f"  longest single unit: {cyc} cycles ({cyc / 2.4e3:.0f} us at 2.4 GHz), unit {unit} of its launch, "
+              f"{cost} node groups + triangle records; open pixels enumerated: {a[14]}, enumeration passes: {a[15]}")
 
 
 if __name__ == "__main__":

@@ -92,6 +92,8 @@ typedef struct rt_stats {
     uint64_t coop_chunks;    /* k_path chunks run in the cooperative form (four waves sharing the
                                 traversals of one chunk; max_depth > 0 over a deep tree)        */
     uint64_t batch_launches; /* how many of the path_launches were k_batch                           */
+    uint64_t batch_listed;   /* units the most recent k_batch launches listed as costly: the next     */
+                             /* launch starts with them, one pixel per wave (ordering only)           */
 } rt_stats;
 
 /* Replaces the surface/graph set-up of initCUDA (kernel.cu:193-256): creates the

@@ -19,6 +19,7 @@ using namespace rt;
 
 namespace {
 
+constexpr uint32_t kWholeBatchPixels = 160000; // from here on k_batch takes the partition in one launch (rt_render)
 constexpr uint32_t kMinLanePixels = 1u << 16;   // below this a second lane is not worth its launches
 
 thread_local std::string g_err;              // for calls that have no context yet
@@ -76,6 +77,12 @@ struct Lane {
     FbCounts *cnt = nullptr;             // [3]
     uint32_t fb_slots = 0;
     uint32_t fb_seq = 0;                 // path launches so far (set rotation)
+    // unit-order feedback of k_batch (rt_kernels.h BatchFeedback): three sets rotating by launch
+    uint32_t *bheavy[3] = {nullptr, nullptr, nullptr};
+    uint32_t *bflag[3] = {nullptr, nullptr, nullptr};
+    FbCounts *bcnt = nullptr;            // [3]
+    uint32_t bfb_slots = 0;
+    uint32_t bfb_seq = 0;                // k_batch launches so far
 };
 
 struct rt_context {
@@ -92,7 +99,9 @@ struct rt_context {
     std::vector<uint32_t> h_pixmap;
     std::vector<Lane> lanes;             // streams/events live as long as the context
     int n_lanes = 1;                     // lanes in use for the current partition
-    int lanes_wanted = 2;                // 2 measured best (C3, C4); more only add launches
+    int lanes_wanted = 2;                // 2 measured best for k_path (C2); more only add launches
+    bool lanes_forced = false;           // RT_LANES given: k_batch keeps to the lanes too
+    int lanes_used = 1;                  // by the last rt_render
 
     bool have_scene = false, have_cam = false;
     int n_lights = 0;
@@ -104,8 +113,10 @@ struct rt_context {
     int cnt = 0;                         // samples accumulated (kernel.cu:52-54)
 
     // depth 0 over a deep tree (k_batch, rt_kernels.hip): samples per batch
-    int batch_wanted = 64;
+    int batch_wanted = 0;                // RT_BATCH: samples per k_batch launch (0: chosen by the call's sample count)
     uint64_t batch_launches = 0;         // launches of k_batch
+    bool feedback_debug = false;
+    bool batch_feedback = true;          // costly units of one launch go out first, by pixel, in the next (RT_FEEDBACK=0: off)
 
     // stats
     uint64_t samples = 0, primary = 0, launches = 0, timed_launches = 0;
@@ -214,6 +225,18 @@ int alloc_feedback(rt_context *c, Lane &L)
     RT_HIP(c, hipMemset(L.cnt, 0, 3 * sizeof(FbCounts)));
     L.fb_slots = (uint32_t)std::max<size_t>(chunks, 1);
     L.fb_seq = 0;
+    // k_batch: one entry per unit of the smallest shape (2 pixels x 64 samples)
+    // (lane 0 may be given the whole partition: rt_render)
+    const size_t units = ((size_t)(&L == &c->lanes[0] ? c->n_local : L.hi - L.lo) + 1) / 2 + 1;
+    for (int s = 0; s < 3; s++) {
+        if ((rc = dalloc(c, c->part_allocs, L.bheavy[s], units))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.bflag[s], units))) return rc;
+        RT_HIP(c, hipMemset(L.bflag[s], 0, units * sizeof(uint32_t)));
+    }
+    if ((rc = dalloc(c, c->part_allocs, L.bcnt, 3))) return rc;
+    RT_HIP(c, hipMemset(L.bcnt, 0, 3 * sizeof(FbCounts)));
+    L.bfb_slots = (uint32_t)units;
+    L.bfb_seq = 0;
     return RT_OK;
 }
 
@@ -310,6 +333,20 @@ ChunkFeedback next_feedback(Lane &L)
     return f;
 }
 
+// Feedback sets of k_batch rotate by launch: read what the previous launch wrote, write the next
+// set; the set after that is zeroed here, on the lane's stream, for the launch that will write it.
+int next_batch_feedback(rt_context *c, Lane &L, BatchFeedback &f)
+{
+    const int r = (int)((L.bfb_seq + 2u) % 3u), w = (int)(L.bfb_seq % 3u), z = (int)((L.bfb_seq + 1u) % 3u);
+    f.cnt_r = L.bcnt + r; f.heavy_r = L.bheavy[r]; f.flag_r = L.bflag[r];
+    f.cnt_w = L.bcnt + w; f.heavy_w = L.bheavy[w]; f.flag_w = L.bflag[w];
+    f.n_slots = L.bfb_slots;
+    RT_HIP(c, hipMemsetAsync(L.bcnt + z, 0, sizeof(FbCounts), L.stream));
+    RT_HIP(c, hipMemsetAsync(L.bflag[z], 0, (size_t)L.bfb_slots * sizeof(uint32_t), L.stream));
+    L.bfb_seq++;
+    return RT_OK;
+}
+
 // One launch of the path kernel on a lane (one progressive sample of its pixel range),
 // optionally bracketed by HIP events on the lane's stream.
 void timed_path(rt_context *c, Lane &L, const DevView &v, int max_depth)
@@ -381,7 +418,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     // the grid what is resident at once; more blocks would only queue behind those.
     c->max_blocks = std::max(1, prop.multiProcessorCount);
     if (const char *e = std::getenv("RT_MAX_BLOCKS")) c->max_blocks = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("RT_LANES")) c->lanes_wanted = std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = std::getenv("RT_LANES")) { c->lanes_wanted = std::max(1, std::min(8, std::atoi(e))); c->lanes_forced = true; }
     int rc = RT_OK;
     c->lanes.resize((size_t)c->lanes_wanted);
     for (Lane &L : c->lanes) {
@@ -392,6 +429,8 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
         }
     }
     if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_FEEDBACK")) c->batch_feedback = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RT_FEEDBACK_DEBUG")) c->feedback_debug = std::atoi(e) != 0;
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -532,21 +571,35 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
         // rt_kernels.hip): camera rays from predicted counters, shadow rays and the running mean
         // of a unit without leaving the wave.  The lanes' launches follow each other on their own
         // streams, so one lane's tail is filled by the other's next launch.
-        const int want = n_samples >= 64 ? 32 : 16;
-        const uint32_t cap = (uint32_t)std::min(std::max(n_samples, 1), std::min(c->batch_wanted, want));
+        // Measured (tools/partition_rehearsal.py, C3 and C4): 64 samples per launch beat 32 and
+        // 16 (fewer tails, two-pixel units); one launch over the whole partition beats two lanes
+        // from about 160k pixels on (14.8 vs 15.4 ms C3, 59.4 vs 61.7 ms C4), below that the
+        // second lane's launches fill the first's tail (2.3 vs 2.7 ms on an eighth of C3).
+        const int want = c->batch_wanted ? c->batch_wanted : n_samples >= 64 ? 64 : n_samples >= 32 ? 32 : 16;
+        const uint32_t cap = (uint32_t)std::min(std::max(n_samples, 1), want);
+        const bool whole = c->n_lanes > 1 && !c->lanes_forced && c->n_local >= kWholeBatchPixels;
+        const int nb = whole ? 1 : c->n_lanes;
+        c->lanes_used = nb;
         RT_HIP(c, hipEventRecord(c->ev_r0, s0));
-        for (int k = 0; k < c->n_lanes; k++)
+        for (int k = 0; k < nb; k++)
             RT_HIP(c, hipStreamWaitEvent(c->lanes[k].stream, c->ev_r0, 0));
         for (int done = 0; done < n_samples;) {
             const uint32_t S = (uint32_t)std::min<int>((int)cap, n_samples - done);
-            for (int k = 0; k < c->n_lanes; k++) {
+            for (int k = 0; k < nb; k++) {
                 Lane &ln = c->lanes[k];
-                if (ln.hi <= ln.lo) continue;
+                const uint32_t lo = ln.lo, hi = whole ? c->lanes[c->n_lanes - 1].hi : ln.hi;
+                if (hi <= lo) continue;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (c->timing) { e0 = next_event(c); e1 = next_event(c); }
+                BatchFeedback f{};
+                if (c->batch_feedback) {
+                    int rc = next_batch_feedback(c, ln, f);
+                    if (rc) return rc;
+                }
                 if (e0) (void)hipEventRecord(e0, ln.stream);
-                launch_batch(ln.stream, c->v, ln.lo, ln.hi - ln.lo, S, c->cnt, c->max_blocks, ln.ctl,
-                             ln.ctl->work[ln.seq & 1u], ln.ctl->work[(ln.seq + 1u) & 1u]);
+                launch_batch(ln.stream, c->v, lo, hi - lo, S, c->cnt, c->max_blocks, ln.ctl,
+                             ln.ctl->work[ln.seq & 1u], ln.ctl->work[(ln.seq + 1u) & 1u],
+                             c->batch_feedback ? &f : nullptr);
                 ln.seq++;
                 if (e1) (void)hipEventRecord(e1, ln.stream);
                 c->launches++;
@@ -557,11 +610,12 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             c->samples += (uint64_t)c->n_local * S;
             c->primary += (uint64_t)c->n_local * S;
         }
-        for (int k = 0; k < c->n_lanes; k++) {
+        for (int k = 0; k < nb; k++) {
             RT_HIP(c, hipEventRecord(c->lanes[k].done, c->lanes[k].stream));
             RT_HIP(c, hipStreamWaitEvent(s0, c->lanes[k].done, 0));
         }
     } else {
+    c->lanes_used = c->n_lanes;
     RT_HIP(c, hipEventRecord(c->ev_r0, s0));                 // fork: lanes start after the main stream
     for (int k = 0; k < c->n_lanes; k++)
         RT_HIP(c, hipStreamWaitEvent(c->lanes[k].stream, c->ev_r0, 0));
@@ -594,6 +648,16 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     RT_HIP(c, hipStreamSynchronize(s0));          // cudaStreamSynchronize, kernel.cu:123
     RT_HIP(c, hipGetLastError());
     resolve_events(c);
+    if (c->feedback_debug) {                                 // RT_FEEDBACK_DEBUG=1: what the last k_batch launches listed
+        for (int k = 0; k < c->n_lanes; k++) {
+            Lane &ln = c->lanes[k];
+            if (!ln.bcnt || !ln.bfb_seq) continue;
+            FbCounts h{};
+            RT_HIP(c, hipMemcpy(&h, ln.bcnt + (ln.bfb_seq + 2u) % 3u, sizeof h, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "rt: lane %d launch %u listed %u units, cost total %llu, shape %u\n", k,
+                         ln.bfb_seq, h.n_heavy, (unsigned long long)h.total, h.pad);
+        }
+    }
     float ms = 0.0f;
     RT_HIP(c, hipEventElapsedTime(&ms, c->ev_r0, c->ev_r1));
     c->render_ms += ms;
@@ -788,9 +852,17 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->path_ms = c->path_ms;
     st->render_ms = c->render_ms;
     st->n_prims = c->n_prims;
-    st->streams = (uint64_t)c->n_lanes;
+    st->streams = (uint64_t)c->lanes_used;
     st->coop_chunks = coop_total;
     st->batch_launches = c->batch_launches;
+    st->batch_listed = 0;
+    for (int k = 0; k < c->n_lanes; k++) {
+        const Lane &ln = c->lanes[k];
+        if (!ln.bcnt || !ln.bfb_seq) continue;
+        FbCounts h{};
+        RT_HIP(c, hipMemcpy(&h, ln.bcnt + (ln.bfb_seq + 2u) % 3u, sizeof h, hipMemcpyDeviceToHost));
+        st->batch_listed += std::min(h.n_heavy, ln.bfb_slots);
+    }
     return RT_OK;
 }
 

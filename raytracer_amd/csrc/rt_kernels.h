@@ -66,6 +66,25 @@ struct ChunkFeedback {
     uint32_t n_slots;                    // entries of the heavy / early arrays (= chunks of the range)
 };
 
+// Unit-order feedback of k_batch.  A unit's cost (node groups + triangle records of all its
+// traversals) is stable from one batch of samples to the next -- same pixels -- and a few units on
+// silhouettes cost fifty times the mean: a launch cannot end before its longest unit does.  So every
+// launch lists the units that cost >= heavy_cost, and the next launch of the same shape starts with
+// them, split by pixel: each pixel of a listed unit is a task of its own (a quarter of the lanes,
+// but rays through one pixel walk far less of the tree together than rays along a silhouette), so
+// four waves share what one wave would have carried.  Sets rotate by launch (r: written by the
+// previous launch, w: written now, z: zeroed by the host for the launch after).  Only an ordering
+// hint: every pixel-sample is processed exactly once whatever the sets hold.
+struct BatchFeedback {
+    const FbCounts *cnt_r;               // n_heavy, pad = 1 + ss_log2 of the launch that wrote the set, total
+    const uint32_t *heavy_r;             // unit ids
+    const uint32_t *flag_r;              // per unit: != 0 = listed in heavy_r
+    FbCounts *cnt_w;
+    uint32_t *heavy_w;
+    uint32_t *flag_w;
+    uint32_t n_slots;                    // entries of the arrays
+};
+
 struct DevView {
     int width, height;
     int cnt;                        // 1-based sample index (*cnt of kernel.cu:52-66)
@@ -102,7 +121,8 @@ constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (t
 // kernel: camera rays from predicted counters, the pixels the prediction fails on, shadow rays
 // and the running mean without leaving the wave (k_batch).
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
-                  int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next);
+                  int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
+                  const BatchFeedback *fb);
 
 // Scene::hit on a queue of caller rays (rt_scene_hit).
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

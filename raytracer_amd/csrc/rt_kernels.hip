@@ -1012,6 +1012,7 @@ struct BatchArgs {
     int cnt0;                        // samples accumulated before this batch
     bool occlusion;
     Ctl *ctl;
+    BatchFeedback fb;                // cnt_w == nullptr: no feedback
 };
 
 // What a lane carries across a traversal is parked in LDS (slot i of a lane: st[i * kBlock]),
@@ -1150,6 +1151,7 @@ __device__ __forceinline__ void hard_candidate(uint32_t r, uint32_t &k, uint32_t
 // traced, the framebuffer texels are requested before the shadow rays and used after them, and
 // the running mean reads the samples' radiance from LDS (one owner lane per pixel, in sample
 // order: kernel.cu:65-66,75,77).
+constexpr uint32_t kAllPixels = 0xffffffffu;
 constexpr int kRecRows = 8;                  // pos (3), normal (3), dot(-dir, normal), model
 constexpr int kFuseTmpRows = 14;             // phase P: trace_primary's 5 + 8 of the unit; phase S: 7 per ray
 constexpr int kFuseRows = 2 * kRecRows + kFuseTmpRows;
@@ -1177,9 +1179,12 @@ __device__ __forceinline__ void write_last(const BatchArgs &A, const PrimaryTrac
 
 template <bool CULL>
 __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
+                                           uint32_t only_px, bool skip_listed, uint32_t heavy_cost,
                                            uint32_t lane, uint32_t *col, uint32_t *next_counter,
-                                           uint32_t &ticket, Stamps &sp)
+                                           uint32_t &ticket, unsigned long long &cost_sum, Stamps &sp)
 {
+    // only_px = kAllPixels: the whole unit; else only its pixel `only_px` (a listed unit, split by pixel).
+    // skip_listed: units the previous launch listed were handed out pixel by pixel already.
     const DevView &v = A.v;
     const uint32_t L = (uint32_t)v.n_lights;
     const float E = A.T.tv.extent;
@@ -1200,7 +1205,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     for (int h = 0; h < 2; h++) {
         const uint32_t r = (uint32_t)h * 64u + lane;
         const uint32_t pl = A.p0 + (unit << px_log2) + (r & px_mask);
-        todo[h] = pl < p_end && (r >> px_log2) < A.n_samples;
+        todo[h] = pl < p_end && (r >> px_log2) < A.n_samples && (only_px == kAllPixels || (r & px_mask) == only_px);
         const uint32_t p = min(pl, p_end - 1u);
         pix[h] = v.pixmap[p];
         base_c[h] = v.rng_ctr[p];
@@ -1209,9 +1214,12 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         dhat[h] = last ? last : 3u + L;
         col[(h * kRecRows + 7) * kBlock] = 0xffffffffu;     // no record yet: model = -1
     }
+    const bool listed = skip_listed && A.fb.flag_r[unit] != 0u;
     // the NEXT unit's ticket: drawn behind the prologue's loads, it comes back while this unit is traced
     if (lane == 0)
         ticket = atomicAdd(next_counter, 1u);
+    if (listed)
+        return;                                              // its pixels went out one by one, first
 
     // Phases P and H share ONE call site of the closest-hit traversal (one copy of its loop in the
     // instruction cache).  mode 0, 1: the two prediction rounds; mode 2: the pixels still open
@@ -1380,11 +1388,11 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     // below; one register set for all unit shapes, .x alone in the channel-parallel form)
     float4 prev0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (px_log2 >= 5u) {
-        if (ln <= px_mask && own_pl < p_end) prev0 = v.fb[own_pl];
+        if (ln <= px_mask && own_pl < p_end && (only_px == kAllPixels || ln == only_px)) prev0 = v.fb[own_pl];
     } else {
         const uint32_t q = ln & px_mask, ch = ln >> px_log2;
         const uint32_t pl = A.p0 + (unit << px_log2) + q;
-        if (ch < 3u && pl < p_end) prev0.x = ((const float *)&v.fb[pl])[ch];
+        if (ch < 3u && pl < p_end && (only_px == kAllPixels || q == only_px)) prev0.x = ((const float *)&v.fb[pl])[ch];
     }
     struct RS { v3 pos, normal; float wo_y; int model; v3 le, contrib; float thr; } S[2];
     bool hit[2], cast[2] = {false, false};
@@ -1519,7 +1527,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         for (int h = 0; h < 2; h++) {
             const uint32_t q = (uint32_t)h * 64u + ln;       // second pass only when a wave holds 128 pixels
             const uint32_t pl = A.p0 + (unit << px_log2) + q;
-            if (q <= px_mask && pl < p_end) {
+            if (q <= px_mask && pl < p_end && (only_px == kAllPixels || q == only_px)) {
                 const float *const f0 = (const float *)tmp0;
                 float4 prev = h ? v.fb[pl] : prev0;           // (a wave of 128 pixels: the second texel only now)
                 for (uint32_t smp = 0; smp < A.n_samples; smp++) {
@@ -1539,7 +1547,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         // from the column of the lane that traced it
         const uint32_t q = ln & px_mask, ch = ln >> px_log2;
         const uint32_t pl = A.p0 + (unit << px_log2) + q;
-        if (ch < 3u && pl < p_end) {
+        if (ch < 3u && pl < p_end && (only_px == kAllPixels || q == only_px)) {
             const float *c = (const float *)tmp0 + q + ch * kBlock;
             float prev = prev0.x;
             const uint32_t half = min(A.n_samples, 64u >> px_log2);          // samples held by lanes' first rays
@@ -1556,6 +1564,16 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     }
     if (lane == 0 && n_shadow)
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+    // feedback for the next launch: what this unit cost, and whether it should go out first, by pixel
+    // (a pixel task costs a quarter of the lanes but much less than its unit: listed again from a quarter on)
+    cost_sum += cost;
+    if (A.fb.cnt_w && lane == 0 && cost >= (only_px == kAllPixels ? heavy_cost : heavy_cost >> 2)) {
+        if (atomicExch(&A.fb.flag_w[unit], 1u) == 0u) {
+            const uint32_t slot = atomicAdd(&A.fb.cnt_w->n_heavy, 1u);
+            if (slot < A.fb.n_slots)
+                A.fb.heavy_w[slot] = unit;
+        }
+    }
     // the next unit's phase P writes these rows: every lane's reads above must be done first
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
@@ -1584,33 +1602,70 @@ __global__ __launch_bounds__(kBlock, 4) void k_batch(const BatchArgs A, uint32_t
     sp.start();
     const unsigned long long t_begin = sp.last;
 #endif
-    const uint32_t px = kPathChunk >> A.ss_log2;
+    const uint32_t px_log2 = 7u - A.ss_log2, px = 1u << px_log2;
     const uint32_t n_units = (A.n + px - 1u) / px;
+    // What the previous launch of this shape found costly: those units first, one pixel per task.
+    uint32_t n_listed = 0, heavy_cost = 0xffffffffu;
+    unsigned long long cost_sum = 0ull;
+    if (A.fb.cnt_w) {
+        const FbCounts cr = *A.fb.cnt_r;
+        if (cr.pad == A.ss_log2 + 1u && cr.total) {
+            n_listed = min(cr.n_heavy, A.fb.n_slots);
+            // A unit holds the launch up when it is a good part of what one wave does in the whole
+            // launch: listed from a quarter of a resident wave's share on, and never below eight
+            // times the mean unit cost (splitting costs lanes) or 96 node groups + triangle records
+            const unsigned long long share = cr.total / ((unsigned long long)gridDim.x * (kBlock / 64u));
+            const unsigned long long mean8 = 8ull * cr.total / std::max(n_units, 1u);
+            heavy_cost = (uint32_t)std::min<unsigned long long>(std::max(std::max(share / 4ull, mean8), 96ull), 0x7fffffffull);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            A.fb.cnt_w->pad = A.ss_log2 + 1u;                // (n_heavy and total were zeroed by the host)
+    }
+    // Stage -1: the listed units' pixels (one counter for the whole chip); stages 0..7: this XCD's
+    // band of units, then the other XCDs' bands.  One ticket ahead throughout.
     const uint32_t per = (n_units + 7u) / 8u, xcd = blockIdx.x & 7u;
-    uint32_t stage = 0, y = xcd, base = y * per;
-    uint32_t size = base < n_units ? min(per, n_units - base) : 0u;
-    uint32_t ticket = 0;
-    if (lane == 0)
-        ticket = atomicAdd(&work[y], 1u);
-    for (;;) {
-        uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
-        while (d >= size) {                                  // this band is used up: on to the next XCD's
-            if (++stage >= 8u)
-                break;
-            y = (xcd + stage) & 7u;
+    int stage = n_listed ? -1 : 0;
+    uint32_t base = 0, size = 0, ticket = 0;
+    uint32_t *ctr = nullptr;
+    auto enter = [&](int st) {
+        if (st < 0) {
+            base = 0; size = n_listed << px_log2; ctr = &work[kWorkHeavy];
+        } else {
+            const uint32_t y = (xcd + (uint32_t)st) & 7u;
             base = y * per;
             size = base < n_units ? min(per, n_units - base) : 0u;
+            ctr = &work[y];
+        }
+    };
+    enter(stage);
+    if (lane == 0 && size)
+        ticket = atomicAdd(ctr, 1u);
+    for (;;) {
+        uint32_t d = size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) : 0u;
+        while (d >= size) {                                  // used up: on to the next stage
+            if (++stage >= 8)
+                break;
+            enter(stage);
             d = size;
             if (size) {
                 if (lane == 0)
-                    ticket = atomicAdd(&work[y], 1u);
+                    ticket = atomicAdd(ctr, 1u);
                 d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
             }
         }
-        if (stage >= 8u)
+        if (stage >= 8)
             break;
-        fused_unit<CULL>(A, env, base + d, lane, col, &work[y], ticket, sp);
+        uint32_t unit = base + d, only_px = kAllPixels;
+        if (stage < 0) {
+            // (a listed id is a unit of this shape: the min only keeps a damaged list harmless --
+            // unit n_units has no pixels)
+            unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.heavy_r[d >> px_log2]), n_units);
+            only_px = d & (px - 1u);
+        }
+        fused_unit<CULL>(A, env, unit, only_px, stage >= 0 && n_listed != 0u, heavy_cost, lane, col, ctr, ticket, cost_sum, sp);
     }
+    if (A.fb.cnt_w && lane == 0 && cost_sum)
+        atomicAdd(&A.fb.cnt_w->total, cost_sum);
 #ifdef RT_STAMPS
     sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
     sp.flush(2);
@@ -1846,11 +1901,13 @@ static BatchArgs batch_args(const DevView &v, uint32_t p0, uint32_t n, uint32_t 
 }
 
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
-                  int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next)
+                  int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
+                  const BatchFeedback *fb)
 {
     if (n == 0 || n_samples == 0)
         return;
     BatchArgs A = batch_args(v, p0, n, n_samples, cnt0, ctl);
+    if (fb) A.fb = *fb;
     const uint32_t px = kPathChunk >> A.ss_log2;
     const uint32_t units = (n + px - 1) / px;
     const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * 4u);

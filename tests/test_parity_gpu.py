@@ -603,9 +603,9 @@ def _silhouette_window(got, cfg, cw, ch):
             int(min(max(ys[k] - ch // 2, 0), cfg.height - ch)), cw, ch)
 
 
-def test_full_size_c3_bench_shape(gpu_ctx_factory):
-    """C3 exactly as the bench renders it -- 1920x1080, 64 spp in one call = two batches of 32
-    samples (4 pixels x 32 samples per wave; open pixels take the enumeration's four rounds) --
+def test_full_size_c3_bench_shape(gpu_ctx_factory, monkeypatch):
+    """C3 exactly as the bench renders it -- 1920x1080, 64 spp in one call = one batch of 64
+    samples (2 pixels x 64 samples per wave; open pixels take the enumeration's eight rounds) --
     against the oracle on windows at the silhouette, on the mesh, the ground and the sky."""
     cfg = scenes.c3()
     ctx = gpu_ctx_factory(cfg.width, cfg.height)
@@ -616,11 +616,34 @@ def test_full_size_c3_bench_shape(gpu_ctx_factory):
     ctx.render(cfg.spp, 0)
     st = ctx.stats()
     ctx.set_timing(False)
-    assert cfg.spp == 64 and st.batch_launches == 2 * st.streams   # two 32-sample batches per stream through k_batch
+    assert cfg.spp == 64 and st.batch_launches == st.streams   # one 64-sample batch per stream through k_batch
     got = ctx.read_framebuffer()
     crops = [_silhouette_window(got, cfg, 8, 4), (956, 538, 8, 4), (44, 1042, 8, 4), (904, 4, 8, 2)]
     ref = _check_windows(got, cfg, crops, cfg.spp)
     assert 0 < (ref["prim_id"] >= 0).sum() < len(ref["prim_id"])        # hits and misses both
+    # The first launch measures the mean unit cost, the second lists the units far above it (the
+    # silhouette's), the third hands those out first, one pixel per wave, and skips them in the
+    # bands -- every pixel still gets each sample once.
+    assert st.batch_listed == 0
+    more = (cfg.spp, cfg.spp, 32, 32, 32)                   # (another shape: the 64-sample list is not for it)
+    for i, spp in enumerate(more):
+        ctx.render(spp, 0)
+        assert (ctx.stats().batch_listed > 0) == (i not in (2,))
+    got = ctx.read_framebuffer()
+    _check_windows(got, cfg, crops, cfg.spp + sum(more))
+    # ... and the whole frame, bit for bit, against the same renders with the ordering off
+    monkeypatch.setenv("RT_FEEDBACK", "0")
+    plain = gpu_ctx_factory(cfg.width, cfg.height)
+    monkeypatch.delenv("RT_FEEDBACK")
+    plain.upload_scene(cfg.scene)
+    plain.set_camera(cfg.camera)
+    for spp in (cfg.spp,) + more:
+        plain.render(spp, 0)
+    assert plain.stats().batch_listed == 0
+    ref = plain.read_framebuffer()
+    assert np.array_equal(got["rgba"].view(np.uint32), ref["rgba"].view(np.uint32))
+    assert np.array_equal(got["prim_id"], ref["prim_id"])
+    assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
 
 
 @pytest.fixture(scope="module")

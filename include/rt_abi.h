@@ -41,9 +41,12 @@ typedef struct rt_context rt_context;
  * (Scene/Scene.cu:13-41): the model_size[0] standalone Triangle models, then each
  * Mesh's meshTable.  Models are numbered triangles, meshes, quadrics -- the order
  * initializeScene walks material_type[] / Material[] (Scene/Scene.cu:143-149).
- * Point and directional lights (the delta lights, Scene.cu:93-102) are supported;
- * triangle and environment lights (the MIS branch, Scene.cu:242-284) are outside the hot
- * path: light_size[2..3] have no fields here. */
+ * Point and directional lights (the delta lights, Scene.cu:93-102) and triangle lights
+ * (hit-able area lights: Scene.cu:43-64, emission core/PathTracer.cu:33-52, the MIS branch
+ * Scene.cu:242-284) are supported; a scene with triangle lights renders through the general
+ * path kernel, not the depth-0 batch kernel.  Environment lights (light_size[3]) are outside
+ * the path and have no fields here.
+ * A light hit reports prim_id = n_tris + n_quads + its index. */
 typedef struct rt_scene_desc {
     int32_t n_tri_models;          /* model_size[0]                               */
     int32_t n_meshes;              /* model_size[1]                               */
@@ -66,6 +69,13 @@ typedef struct rt_scene_desc {
     const float *dl_dir;           /* [n_dir_lights][3] DirectionalLight(direction, ..) argument;
                                       normalised as its constructor does (Light.cu:21) */
     const float *dl_illum;         /* [n_dir_lights][3] DirectionalLight::illum (Light.cuh:57) */
+    int32_t n_tri_lights;          /* light_size[2]                               */
+    const float *tl_pos;           /* [n_tri_lights][3][3] TriangleLight(posa, posb, posc, ..) (Light.cuh:71) */
+    const float *tl_illum;         /* [n_tri_lights][3] light_color               */
+    const int32_t *tl_two_side;    /* [n_tri_lights] two (Light.cuh:71,102)       */
+    const int32_t *tl_mat_type;    /* [n_tri_lights] material_type[n_models + k]: the light's own
+                                      Material (Scene.cu:151-153); LAMBERTIAN only (Light.cu:115-125) */
+    const float *tl_color;         /* [n_tri_lights][3] its Lambertian::color     */
 } rt_scene_desc;
 
 /* Camera(pos, lookat, fov, near, far, int2 res, up)          (Camera/Camera.cuh:11).

@@ -160,8 +160,9 @@ typedef struct {
     float t;
     ray_t wo;
     int lightidx;
+    int light_type;
     float pdf_light, pdf_surface;
-    int material;      /* model index standing in for Material* */
+    int material;      /* model index standing in for Material*; n_models + k: triangle light k's */
     int isLight;
     int material_type;
     int prim;          /* not in the reference: primitive index, for the id buffer */
@@ -321,6 +322,77 @@ static int quad_hit(const orc_scene *s, int q, const ray_t *r, rec_t *c)
     return 0;
 }
 
+/* ---------------------------------------------------------------- TriangleLight */
+#define ORC_LIGHT_TRIANGLE 2          /* Light/Light.cuh:16-23 light::TRIANGLE_LIGHT */
+typedef struct { f3 pos[3], normal, illum; int two_side; } tl_t;
+/* Light/Light.cu:35-40: the constructor normalises the member normal. */
+static tl_t tl_load(const orc_scene *s, int k)
+{
+    const float *pp = s->tl_pos + 9 * (size_t)k, *li = s->tl_illum + 3 * (size_t)k;
+    tl_t l;
+    l.pos[0] = mk3(pp[0], pp[1], pp[2]);
+    l.pos[1] = mk3(pp[3], pp[4], pp[5]);
+    l.pos[2] = mk3(pp[6], pp[7], pp[8]);
+    l.normal = normalize3(cross3(sub3(l.pos[1], l.pos[0]), sub3(l.pos[2], l.pos[0])));
+    l.illum = mk3(li[0], li[1], li[2]);
+    l.two_side = s->tl_two_side[k] != 0;
+    return l;
+}
+/* Light/Light.cuh:76-79 (0.5 is a double literal: the halving is exact either way) */
+static float tl_area(const tl_t *l)
+{
+    return (float)(0.5 * (double)length3(cross3(sub3(l->pos[2], l->pos[0]), sub3(l->pos[1], l->pos[0]))));
+}
+/* Light/Light.cuh:81-85 */
+static float tl_pdf(const tl_t *l, float rec_t, f3 wi)
+{
+    if (fabsf(dot3(l->normal, wi)) < 0.001f)
+        return 0.0f;
+    return rec_t * rec_t / (tl_area(l) * fabsf(dot3(l->normal, wi)));
+}
+/* Light/Light.cuh:86-91 */
+static f3 tl_L(const tl_t *l, f3 r)
+{
+    if (l->two_side)
+        return l->illum;
+    return dot3(r, l->normal) > 0 ? l->illum : mk3(0.0f, 0.0f, 0.0f);
+}
+/* Light/Light.cu:68-105 TriangleLight::hit.  The local `normal` of :72 shadows the member: the
+ * record's normal is the UNNORMALISED cross product.  The light's own Material is model index
+ * n_models + k here (Scene.cu:151-153 hands it material_type[] / Material[] entry n_models + k). */
+static int tl_hit(const orc_scene *s, int k, const ray_t *r, rec_t *rec)
+{
+    tl_t l = tl_load(s, k);
+    float t;
+    f3 normal = cross3(sub3(l.pos[0], l.pos[2]), sub3(l.pos[1], l.pos[2]));   /* :72 */
+    float dot_normal_dir = dot3(normal, r->d);                      /* :73 */
+    if (fabsf(dot_normal_dir) < ORC_FLOAT_EPS)                      /* :74 */
+        return 0;
+    t = (-dot3(r->o, normal) + dot3(l.pos[0], normal)) / dot_normal_dir;      /* :77 */
+    f3 rpos = ray_pos(r, t);                                        /* :79 */
+    float S = 2.0f * tl_area(&l);                                   /* :81 */
+    float s1 = length3(cross3(sub3(rpos, l.pos[0]), sub3(rpos, l.pos[1])));   /* :82 */
+    float s2 = length3(cross3(sub3(rpos, l.pos[2]), sub3(rpos, l.pos[0])));   /* :83 */
+    float s3 = length3(cross3(sub3(rpos, l.pos[2]), sub3(rpos, l.pos[1])));   /* :84 */
+    if (fabsf(s1 + s2 + s3 - S) > 0.001f)                           /* :87 */
+        return 0;
+    float m1 = s3 / S, m2 = s2 / S, m3 = 1.0f - m1 - m2;            /* :90 */
+    if (t > ORC_FLOAT_EPS && t < rec->t) {                          /* :92 */
+        int n_models = s->n_tri_models + s->n_meshes + s->n_quads;
+        rec->material = n_models + k;                               /* :94 */
+        rec->material_type = s->tl_mat_type[k];                     /* :95 */
+        rec->t = t;
+        rec->normal = l.two_side ? (dot3(normal, r->d) > 0 ? neg3(normal) : normal) : normal; /* :97 */
+        rec->pos = ray_pos(r, t);                                   /* :98 */
+        rec->isLight = 1;                                           /* :99 */
+        rec->tangent = normalize3(add3(scale3(sub3(l.pos[1], l.pos[0]), m2),
+                                       scale3(sub3(l.pos[2], l.pos[0]), m3)));  /* :100 */
+        rec->prim = s->n_tris + s->n_quads + k;
+        return 1;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------- Scene::hit */
 /* Scene/Scene.cu:8-67 with Mesh::hit (Model/Model.cu:287-313) inlined. */
 static int scene_hit(const orc_scene *s, const ray_t *r, rec_t *rec)
@@ -343,7 +415,11 @@ static int scene_hit(const orc_scene *s, const ray_t *r, rec_t *rec)
     }
     for (int j = 0; j < s->n_quads; j++)                            /* :31-37 */
         quad_hit(s, j, r, rec);
-    /* triangle lights (:43-64): light_size[2] == 0 in scope */
+    for (int j = 0; j < s->n_tri_lights; j++)                       /* :43-58 */
+        if (tl_hit(s, j, r, rec)) {
+            rec->lightidx = j;                                      /* :54 */
+            rec->light_type = ORC_LIGHT_TRIANGLE;                   /* :55 */
+        }
     return rec->t > 0.001f && rec->t < ORC_INF - 0.1f;              /* :66 */
 }
 
@@ -480,7 +556,9 @@ static float lambert_pdf(f3 wo, f3 wi)
 
 static f3 model_color(const orc_scene *s, int model)
 {
-    const float *c = s->model_color + 3 * (size_t)model;
+    int n_models = s->n_tri_models + s->n_meshes + s->n_quads;
+    const float *c = model < n_models ? s->model_color + 3 * (size_t)model
+                                      : s->tl_color + 3 * (size_t)(model - n_models);
     return mk3(c[0], c[1], c[2]);
 }
 
@@ -547,8 +625,9 @@ static f3 eval_direct_delta(const orc_scene *s, int type, int j, rec_t rec, orc_
     if (!is_black(f)) {                                             /* :224 */
         cnt->shadow++;
         if (scene_hit(s, &r, &light_rec)) {                         /* :225 */
-            /* H3: idx is uninitialised for delta lights; lightidx stays -1 and the
-             * comparison is restated as never-equal. */
+            /* H3: `idx` is uninitialised for delta lights (Scene.cu:78, set only at :107,111);
+             * `light_rec.lightidx == idx` is restated as never true for them, also when the
+             * shadow ray's closest hit is a triangle light. */
             blocked = length3(sub3(light_rec.pos, r.o)) < length3(sub3(r.o, lpos)) - 0.01f; /* :227 */
         }
     }
@@ -560,6 +639,80 @@ static f3 eval_direct_delta(const orc_scene *s, int type, int j, rec_t rec, orc_
     if (!is_black(f) && !blocked && !is_black(color)) {             /* :236 */
         color = div3s(mul3(color, f), rec.pdf_light);               /* :240 isDelta */
         res = color;
+    }
+    return res;
+}
+
+/* Material/Object.cu:74-104 Material::PDF -> material.cu:79-82 */
+static float rec_pdf(const rec_t *rec, f3 wo, f3 wi)
+{
+    if (rec->material_type != ORC_MAT_LAMBERTIAN)
+        return 0.0f;
+    return lambert_pdf(world2local(rec->normal, rec->tangent, wo),
+                       world2local(rec->normal, rec->tangent, wi));
+}
+
+#define POWER_HEURISTIC(x, y) ((x) * (x) / ((x) * (x) + (y) * (y)))   /* Scene/Scene.cuh:5-7 */
+
+/* Scene/Scene.cu:205-287 evaluateDirectLight for triangle light k (isDelta = false, idx = k),
+ * with TriangleLight::lightIllumi (Light/Light.cu:47-65) inlined.  rec is by value. */
+static f3 eval_direct_area(const orc_scene *s, int k, rec_t rec, f2 sample_light, f2 sample_brdf,
+                           orc_counts *cnt)
+{
+    const int idx = k;
+    tl_t l = tl_load(s, k);
+    /* lightIllumi, Light.cu:49-64 */
+    float sq_x = sqrtf(sample_light.x);
+    f3 tri_sample = mk3(1 - sq_x, sample_light.y * sq_x, 0);
+    tri_sample.z = 1.0f - tri_sample.x - tri_sample.y;
+    f3 lp = add3(add3(scale3(l.pos[0], tri_sample.x), scale3(l.pos[1], tri_sample.y)),
+                 scale3(l.pos[2], tri_sample.z));                   /* Light.cu:44 */
+    ray_t r = mk_ray(lp, sub3(rec.pos, lp));                        /* Light.cu:56 */
+    rec.pdf_light = tl_pdf(&l, length3(sub3(rec.pos, lp)), r.d);    /* Light.cu:58-63 */
+    f3 color = tl_L(&l, r.d);                                       /* Light.cu:64 */
+
+    f3 lpos = r.o;                                                  /* Scene.cu:213 */
+    rec_t light_rec;
+    rec_init(&light_rec);
+    int blocked = 0;
+    r = rec_spawn_ray(&rec, neg3(r.d));                             /* :218 */
+    f3 f = scale3(rec_f(s, &rec, neg3(rec.wo.d), r.d), fabsf(dot3(rec.normal, r.d))); /* :222 */
+    if (!is_black(f)) {                                             /* :224 */
+        cnt->shadow++;
+        if (scene_hit(s, &r, &light_rec))                           /* :225-228 */
+            blocked = light_rec.lightidx == idx
+                          ? 0
+                          : (length3(sub3(light_rec.pos, r.o)) < length3(sub3(r.o, lpos)) - 0.01f);
+    }
+    f3 res = mk3(0.0f, 0.0f, 0.0f);
+    if (rec.pdf_light < 0.001f)                                     /* :233 */
+        return mk3(0.0f, 0.0f, 0.0f);
+    if (!is_black(f) && !blocked && !is_black(color)) {             /* :236 */
+        rec.pdf_surface = rec_pdf(&rec, neg3(rec.wo.d), r.d);       /* :244 */
+        float weight = POWER_HEURISTIC(rec.pdf_light, rec.pdf_surface);   /* :245 */
+        weight /= rec.pdf_light;                                    /* :246 */
+        color = scale3(mul3(color, f), weight);                     /* :247 */
+        res = color;
+    }
+    f3 wi;
+    float weight = 1.0f;
+    f = rec_sample_f(s, &rec, neg3(rec.wo.d), &wi, &rec.pdf_surface, sample_brdf);   /* :258 */
+    f = scale3(f, fabsf(dot3(rec.normal, wi)));                     /* :259 */
+    r = rec_spawn_ray(&rec, wi);                                    /* :260 */
+    rec.t = ORC_INF;                                                /* :262 */
+    rec.lightidx = -1;                                              /* :263 */
+    if (!is_black(f) && rec.pdf_surface > 0.001f) {                 /* :264 */
+        /* :266 isSpecular() is false for every material in scope */
+        float pdf = tl_pdf(&l, rec.t, wi);                          /* :268, with rec.t = INF */
+        if (fabsf(pdf) < 0.01f)                                     /* :269 */
+            return res;
+        weight = POWER_HEURISTIC(rec.pdf_surface, pdf);             /* :271 */
+        f3 lc = mk3(0.0f, 0.0f, 0.0f);
+        cnt->shadow++;
+        if (scene_hit(s, &r, &rec) && rec.lightidx == idx)          /* :275 */
+            lc = tl_L(&l, neg3(wi));                                /* :277 */
+        /* else getLe(r) = BLACK (Light.cuh:94) */
+        res = add3(res, div3s(scale3(mul3(lc, f), weight), rec.pdf_surface));   /* :282 */
     }
     return res;
 }
@@ -637,7 +790,7 @@ static void rng_uniform4(rng_t *g, float out[4])
 }
 
 /* Scene/Scene.cu:69-124 sampleAllLight: one curand_uniform4 per light (:87),
- * light types in enum order; point and directional lights in scope. */
+ * light types in enum order; point, directional and triangle lights in scope. */
 static f3 sample_all_light(const orc_scene *s, const rec_t *rec, rng_t *g, orc_counts *cnt)
 {
     f3 res = mk3(0.0f, 0.0f, 0.0f);
@@ -650,6 +803,12 @@ static f3 sample_all_light(const orc_scene *s, const rec_t *rec, rng_t *g, orc_c
         float tmp[4];
         rng_uniform4(g, tmp);
         res = add3(res, eval_direct_delta(s, 1, j, *rec, cnt));
+    }
+    for (int j = 0; j < s->n_tri_lights; j++) {             /* light::TRIANGLE_LIGHT */
+        float tmp[4];
+        rng_uniform4(g, tmp);                               /* :87-89 */
+        f2 sample_light = { tmp[0], tmp[1] }, sample_surface = { tmp[2], tmp[3] };
+        res = add3(res, eval_direct_area(s, j, *rec, sample_light, sample_surface, cnt));
     }
     return res;
 }
@@ -683,7 +842,13 @@ static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_
             cnt->bounce++;
         }
         rec.wo = r;                                                 /* :32 */
-        /* :33-62 emission: triangle/environment lights only, out of scope */
+        /* :33-52 emission of a triangle light the camera ray (or, with specular materials --
+         * none in scope -- a specular bounce) lands on; :53-61 environment light: out of scope */
+        if (bounces == 0 && ishit && rec.isLight && rec.light_type >= ORC_LIGHT_TRIANGLE &&
+            rec.lightidx >= 0 && rec.lightidx < s->n_tri_lights) {
+            tl_t l = tl_load(s, rec.lightidx);
+            res = add3(res, mul3(beta, tl_L(&l, neg3(r.d))));       /* :47 */
+        }
         if (!ishit || bounces > max_depth)                          /* :64 */
             break;
         int specular = rec.material_type & ORC_MAT_SPECULAR_BIT;    /* :67 */

@@ -61,6 +61,12 @@ typedef struct orc_scene {
     int32_t n_dir_lights;     /* light_size[1] */
     const float *dl_dir;      /* [n_dir_lights][3] DirectionalLight constructor argument */
     const float *dl_illum;    /* [n_dir_lights][3] */
+    int32_t n_tri_lights;     /* light_size[2] */
+    const float *tl_pos;      /* [n_tri_lights][3][3] TriangleLight(posa, posb, posc, ..) (Light.cuh:71) */
+    const float *tl_illum;    /* [n_tri_lights][3]    light_color */
+    const int32_t *tl_two_side; /* [n_tri_lights]     two */
+    const int32_t *tl_mat_type; /* [n_tri_lights]     material_type[n_models + k] (Scene.cu:151-153) */
+    const float *tl_color;    /* [n_tri_lights][3]    Lambertian::color of Material[n_models + k] */
 } orc_scene;
 
 /* The 7 constructor arguments of Camera (reference Camera/Camera.cuh:11). */
@@ -74,7 +80,8 @@ typedef struct orc_camera_args {
 
 typedef struct orc_counts {
     uint64_t primary;   /* camera rays traced                                   */
-    uint64_t shadow;    /* shadow rays actually cast (Scene.cu:224-225)         */
+    uint64_t shadow;    /* shadow rays actually cast (Scene.cu:224-225) and the BRDF-sampled
+                           rays of the area lights' MIS branch (Scene.cu:275)   */
     uint64_t bounce;    /* Scene::hit calls at bounces >= 1 whose result is used */
 } orc_counts;
 

@@ -378,6 +378,41 @@ __device__ __forceinline__ void fill_sphere_hit(const SphereRec &S, const Ray &r
     h.model = S.model;
 }
 
+// Winner-only part of TriangleLight::hit (Light/Light.cu:90-100) for the accepted t.  The
+// record's normal is the unnormalised cross product of Light.cu:72 (it shadows the member),
+// flipped towards the ray for two-sided lights (:97).
+__device__ __forceinline__ void fill_light_hit(const TriLightRec &L, const Ray &r, float t, Hit &h)
+{
+    const TriRec &T = L.T;
+    v3 p = ray_pos(r, t);                                              // :79
+    v3 ta = mk3(T.ax, T.ay, T.az), tb = mk3(T.bx, T.by, T.bz), tc = mk3(T.cx, T.cy, T.cz);
+    float s2 = length(cross(sub(p, tc), sub(p, ta)));                  // :83
+    float s3 = length(cross(sub(p, tc), sub(p, tb)));                  // :84
+    float m1 = s3 / T.S, m2 = s2 / T.S, m3 = 1.0f - m1 - m2;           // :90
+    v3 n = mk3(T.nx, T.ny, T.nz);
+    h.normal = L.two_side ? (dot(n, r.d) > 0 ? neg(n) : n) : n;        // :97
+    h.pos = ray_pos(r, t);                                             // :98
+    h.tangent = normalize(add(scale(mk3(L.e1[0], L.e1[1], L.e1[2]), m2),
+                              scale(mk3(L.e2[0], L.e2[1], L.e2[2]), m3)));   // :100
+    h.color = mk3(-1.0f, -1.0f, -1.0f);
+    h.model = L.model;
+}
+// TriangleLight::PDF (Light/Light.cuh:81-85) and ::L (:86-91)
+__device__ __forceinline__ float light_pdf(const TriLightRec &L, float rec_t, v3 wi)
+{
+    const float c = fabsf(dot(mk3(L.normal[0], L.normal[1], L.normal[2]), wi));
+    if (c < 0.001f)
+        return 0.0f;
+    return rec_t * rec_t / (L.area * c);
+}
+__device__ __forceinline__ v3 light_L(const TriLightRec &L, v3 r)
+{
+    const v3 illum = mk3(L.illum[0], L.illum[1], L.illum[2]);
+    if (L.two_side)
+        return illum;
+    return dot(r, mk3(L.normal[0], L.normal[1], L.normal[2])) > 0 ? illum : mk3(0.0f, 0.0f, 0.0f);
+}
+
 // World-space position the reference stores in rec.pos for a hit (triangle:
 // Model.cu:129; sphere: Model.cu:382,394) -- what the shadow test reads (Scene.cu:227).
 __device__ __forceinline__ v3 hit_pos_sphere(const SphereRec &S, const Ray &r, float t0)

@@ -98,8 +98,9 @@ struct DevView {
     int sorted_planes;              // 1: waves whose rays share an octant read the boxes' planes pre-ordered
     const ModelRec *models;
     const SphereRec *spheres;
-    const LightRec *lights;
-    int n_tris, n_spheres, n_lights;
+    const LightRec *lights;         // delta lights (point, then directional)
+    const TriLightRec *tlights;     // triangle lights: hit-able (Scene.cu:43-64), sampled with MIS (Scene.cu:242-284)
+    int n_tris, n_spheres, n_lights, n_tlights;
     // persistent per local pixel
     const uint32_t *pixmap;         // local index -> global pixel index y*W + x
     uint32_t *rng_ctr;              // next Philox draw of the pixel's stream

@@ -191,6 +191,8 @@ struct TravArgs {
     const SphereRec *spheres;
     int n_tris, n_spheres;
     int sorted_planes;               // 0: always the generic node test (RT_SORTED=0, validation)
+    const TriLightRec *tlights;      // traverse<.., LIGHTS = true> only
+    int n_tlights;
 };
 struct P4 { uint32_t v[4]; };        // one axis' planes of a node group's four boxes (float bits)
 
@@ -289,7 +291,7 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
 // lvloff: lane l holds the first group of level l.
 // COOP: called by all four waves of the block with identical rays; s_best is the block's
 // LDS merge array (128 entries).  Every wave returns the block's common answer.
-template <bool CULL, bool COOP, bool ORDER = true>
+template <bool CULL, bool COOP, bool ORDER = true, bool LIGHTS = false>
 __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, RayPair &r,
                                          uint32_t lane, uint32_t wib,
                                          unsigned long long *s_best, uint32_t &cost, Stamps &sp)
@@ -477,6 +479,22 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         if (sphere_hit(S, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
             r.best.y = t;
             r.idy = A.n_tris + s;
+        }
+    }
+    // triangle lights after every model (Scene.cu:43-58), strict < again; a hit reports the
+    // light's id n_tris + n_quads + k (what rec.lightidx = k, rec.isLight say in the reference)
+    if (LIGHTS) {
+        for (int k = 0; k < A.n_tlights; k++) {
+            const TriRec T = load_uniform(&A.tlights[k].T);
+            float t;
+            if (tri_hit(T, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
+                r.best.x = t;
+                r.idx = T.orig;
+            }
+            if (tri_hit(T, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
+                r.best.y = t;
+                r.idy = T.orig;
+            }
         }
     }
 }
@@ -865,6 +883,312 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
     }
 }
 
+// ------------------------------------------------------------------ scenes with triangle lights
+// The same chunk of 128 pixels, for scenes that hold TriangleLights.  What changes
+// against path_chunk:
+//   * every ray's closest hit also tests the lights, after the models (traverse<.., LIGHTS>);
+//   * the camera ray's hit on a light adds its emission (PathTracer.cu:33-52);
+//   * a light's surface is shaded like any other (its own Lambertian Material, the unnormalised
+//     normal of Light.cu:72,97);
+//   * Scene::sampleAllLight (Scene.cu:69-124) goes on after the delta lights with one MIS
+//     estimate per triangle light (Scene.cu:205-287, isDelta = false): a shadow ray towards a
+//     point sampled on the light (phase A) and a ray along the BRDF's own sample (phase B), both
+//     closest-hit queries whose verdict needs `lightidx == idx`;
+//   * no occlusion shortcut and no LDS stash: this is the feature path, kept plain.  The bench
+//     configurations (delta lights only) never come here.
+struct AreaState {
+    uint32_t draw0;                  // Philox draw of this bounce's tmp (PathTracer.cu:27); light q draws draw0 + 1 + q
+    float wo_y;
+    Hit H;
+    v3 le, cur, contrib;             // sampleAllLight's res; the current light's res; the term under test
+    float thr;
+    bool go_on;                      // the current area light passed `pdf_light >= 0.001` (Scene.cu:233)
+    v3 beta, res;
+};
+
+template <bool CULL>
+__device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane)
+{
+    const DevView &v = A.v;
+    const int Ld = v.n_lights, La = v.n_tlights, L = Ld + La;
+    const int n_models_prims = v.n_tris + v.n_spheres;       // first light id
+    const float E = A.T.tv.extent;
+    uint32_t cost = 0, n_shadow = 0, n_bounce = 0;
+    Stamps sp0;
+    auto pixel_of = [&](int h) { return A.p0 + min(chunk * kPathChunk + (uint32_t)h * 64u + lane, A.n - 1u); };
+    bool mine[2], alive[2], ishit[2] = {false, false}, cast[2] = {false, false};
+    AreaState S[2];
+    uint32_t draw[2];
+    const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
+    RayPair w;
+    auto trace = [&](const v3 o[2], const v3 d[2], const bool live[2]) {
+        pair_set(w, o, d, inf2, none2, live, E);
+        traverse<CULL, false, true, true>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp0);
+    };
+    auto ray_of = [&](int h) {
+        Ray r;
+        r.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+        r.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+        return r;
+    };
+    // rec.pos of the closest hit of the ray just traced (Scene.cu:227 reads it)
+    auto hit_pos = [&](int h, const Ray &sr, float best, int32_t sid) {
+        return (sid >= v.n_tris && sid < n_models_prims) ? hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best)
+                                                         : ray_pos(sr, best);
+    };
+    v3 ro[2], rd[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        mine[h] = chunk * kPathChunk + (uint32_t)h * 64u + lane < A.n;
+        alive[h] = mine[h];
+        const uint32_t p = pixel_of(h), pix = v.pixmap[p];
+        float u[4];
+        draw[h] = v.rng_ctr[p];
+        pixel_uniform4(pix, draw[h], u);                     // kernel.cu:67 (H4)
+        draw[h] += 1u;
+        int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
+        Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
+        ro[h] = r.o; rd[h] = r.d;
+        S[h] = AreaState{};
+        S[h].beta = mk3(1.0f, 1.0f, 1.0f);
+        S[h].res = mk3(0.0f, 0.0f, 0.0f);
+    }
+    for (int bounce = 0;; bounce++) {
+        // ---- closest hit of this bounce: PathTracer.cu:27-64
+        trace(ro, rd, alive);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float t = h ? w.best.y : w.best.x;
+            const int32_t id = h ? w.idy : w.idx;
+            ishit[h] = alive[h] && scene_ishit(t) && id >= 0;
+            S[h].le = mk3(0.0f, 0.0f, 0.0f);
+            if (!alive[h])
+                continue;
+            const uint32_t p = pixel_of(h);
+            if (bounce == 0) {
+                v.first_id[p] = id;
+                v.first_t[p] = t;
+            }
+            S[h].draw0 = draw[h];
+            draw[h] += 1u + (ishit[h] ? (uint32_t)L : 0u);   // tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
+            if (!ishit[h]) {                                 // PathTracer.cu:64
+                finalize_path(v, p, S[h].res);
+                alive[h] = false;
+                continue;
+            }
+            const Ray r = ray_of(h);
+            if (id >= n_models_prims) {
+                const TriLightRec &Lr = v.tlights[id - n_models_prims];
+                fill_light_hit(Lr, r, t, S[h].H);
+                if (bounce == 0)                             // PathTracer.cu:33-47 (no specular materials in scope)
+                    S[h].res = add(S[h].res, mul(S[h].beta, light_L(Lr, neg(r.d))));
+            } else {
+                fill_hit(v, r, id, S[h].H);
+            }
+            S[h].wo_y = local_y(S[h].H, neg(r.d));
+        }
+        if (__ballot(ishit[0] | ishit[1])) {
+            // ---- Scene::sampleAllLight: delta lights (Scene.cu:93-102)
+            for (int j = 0; j < Ld; j++) {
+                const LightRec light = load_uniform(&v.lights[j]);
+                v3 so[2], sd[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    cast[h] = false;
+                    so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+                    if (ishit[h]) {
+                        LightSample s = sample_point_light(S[h].H, v.models[S[h].H.model], S[h].wo_y, light);
+                        cast[h] = s.cast;
+                        so[h] = s.sr.o; sd[h] = s.sr.d;
+                        S[h].thr = s.thr;
+                        S[h].contrib = s.contrib;
+                    }
+                }
+                const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+                if (!(c0 | c1))
+                    continue;
+                n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+                trace(so, sd, cast);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (!cast[h])
+                        continue;
+                    const float best = h ? w.best.y : w.best.x;
+                    const int32_t sid = h ? w.idy : w.idx;
+                    bool blocked = false;                    // H3: `lightidx == idx` never true for delta lights
+                    if (scene_ishit(best) && sid >= 0) {
+                        const Ray sr = ray_of(h);
+                        blocked = length(sub(hit_pos(h, sr, best, sid), sr.o)) < S[h].thr;   // Scene.cu:227
+                    }
+                    if (!blocked)
+                        S[h].le = add(S[h].le, S[h].contrib);
+                }
+            }
+            // ---- triangle lights: Scene.cu:103-108 -> evaluateDirectLight(.., idx = k, isDelta = false)
+            for (int k = 0; k < La; k++) {
+                const TriLightRec &Lr = v.tlights[k];
+                const v3 p0 = mk3(Lr.T.ax, Lr.T.ay, Lr.T.az), p1 = mk3(Lr.T.bx, Lr.T.by, Lr.T.bz),
+                         p2 = mk3(Lr.T.cx, Lr.T.cy, Lr.T.cz);
+                v3 so[2], sd[2];
+                // phase A: TriangleLight::lightIllumi (Light.cu:47-65), shadow ray, light term
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    cast[h] = false;
+                    so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].cur = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].contrib = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].go_on = false;
+                    if (!ishit[h])
+                        continue;
+                    float u[4];
+                    pixel_uniform4(v.pixmap[pixel_of(h)], S[h].draw0 + 1u + (uint32_t)(Ld + k), u);   // Scene.cu:87-89
+                    const Hit &H = S[h].H;
+                    const ModelRec &M = v.models[H.model];
+                    const float sq_x = sqrtf(u[0]);                                   // Light.cu:49
+                    v3 ts = mk3(1 - sq_x, u[1] * sq_x, 0.0f);
+                    ts.z = 1.0f - ts.x - ts.y;
+                    const v3 lp = add(add(scale(p0, ts.x), scale(p1, ts.y)), scale(p2, ts.z));   // Light.cu:44
+                    const Ray wi = make_ray(lp, sub(H.pos, lp));                      // Light.cu:56
+                    const float pdf_light = light_pdf(Lr, length(sub(H.pos, lp)), wi.d);   // Light.cu:58-61
+                    const v3 color = light_L(Lr, wi.d);                               // Light.cu:64
+                    const Ray sr = spawn_ray(H, neg(wi.d));                           // Scene.cu:218
+                    const v3 f = scale(rec_f_y(H, M, S[h].wo_y, sr.d), fabsf(dot(H.normal, sr.d)));   // :222
+                    cast[h] = !is_black(f);                                           // :224
+                    so[h] = sr.o; sd[h] = sr.d;
+                    S[h].thr = length(sub(sr.o, lp)) - 0.01f;                         // :227 rhs
+                    S[h].go_on = !(pdf_light < 0.001f);                               // :233
+                    if (S[h].go_on && cast[h] && !is_black(color)) {                  // :236
+                        const float wy = local_y(H, sr.d);
+                        const float pdf_surface = wy > +0.0f ? wy * kInvPi : 0.0f;    // :244, material.cu:79-82
+                        float weight = pdf_light * pdf_light / (pdf_light * pdf_light + pdf_surface * pdf_surface);   // :245
+                        weight /= pdf_light;                                          // :246
+                        S[h].contrib = scale(mul(color, f), weight);                  // :247
+                    }
+                }
+                {
+                    const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+                    if (c0 | c1) {
+                        n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+                        trace(so, sd, cast);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (!cast[h])
+                                continue;
+                            const float best = h ? w.best.y : w.best.x;
+                            const int32_t sid = h ? w.idy : w.idx;
+                            bool blocked = false;
+                            if (scene_ishit(best) && sid >= 0 && sid != n_models_prims + k) {   // :227 lightidx == idx
+                                const Ray sr = ray_of(h);
+                                blocked = length(sub(hit_pos(h, sr, best, sid), sr.o)) < S[h].thr;
+                            }
+                            if (!blocked)
+                                S[h].cur = S[h].contrib;                              // :249 (BLACK when :236 failed)
+                        }
+                    }
+                }
+                // phase B: the BRDF's own sample (Scene.cu:253-284)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    cast[h] = false;
+                    so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+                    if (!ishit[h] || !S[h].go_on)
+                        continue;
+                    float u[4];
+                    pixel_uniform4(v.pixmap[pixel_of(h)], S[h].draw0 + 1u + (uint32_t)(Ld + k), u);
+                    const Hit &H = S[h].H;
+                    const ModelRec &M = v.models[H.model];
+                    v3 wi;
+                    float pdf_surface;
+                    v3 f = rec_sample_f_y(H, M, S[h].wo_y, wi, pdf_surface, u[2], u[3]);   // :258
+                    f = scale(f, fabsf(dot(H.normal, wi)));                           // :259
+                    const Ray r = spawn_ray(H, wi);                                   // :260
+                    if (is_black(f) || !(pdf_surface > 0.001f))                       // :264
+                        continue;
+                    const float pdf = light_pdf(Lr, kInf, wi);                        // :268 with rec.t = INF (:262)
+                    if (fabsf(pdf) < 0.01f)                                           // :269
+                        continue;
+                    const float weight = pdf_surface * pdf_surface / (pdf_surface * pdf_surface + pdf * pdf);   // :271
+                    S[h].contrib = divs(scale(mul(light_L(Lr, neg(wi)), f), weight), pdf_surface);   // :277,282
+                    cast[h] = true;
+                    so[h] = r.o; sd[h] = r.d;
+                }
+                {
+                    const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+                    if (c0 | c1) {
+                        n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+                        trace(so, sd, cast);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (!cast[h])
+                                continue;
+                            const float best = h ? w.best.y : w.best.x;
+                            const int32_t sid = h ? w.idy : w.idx;
+                            if (scene_ishit(best) && sid == n_models_prims + k)       // :275
+                                S[h].cur = add(S[h].cur, S[h].contrib);               // :282 (else l = getLe = BLACK)
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    if (ishit[h])
+                        S[h].le = add(S[h].le, S[h].cur);                             // Scene.cu:120
+            }
+        }
+
+        // ---- end of the bounce: PathTracer.cu:73-88
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ro[h] = mk3(0.0f, 0.0f, 0.0f); rd[h] = mk3(0.0f, 0.0f, 0.0f);
+            if (!ishit[h])
+                continue;
+            const uint32_t p = pixel_of(h);
+            S[h].res = add(S[h].res, mul(S[h].beta, S[h].le));           // PathTracer.cu:73
+            const Hit &H = S[h].H;
+            const ModelRec &M = v.models[H.model];
+            float u[4];
+            pixel_uniform4(v.pixmap[p], S[h].draw0, u);                  // tmp of PathTracer.cu:27
+            v3 wi;
+            float pdf;
+            v3 f = rec_sample_f_y(H, M, S[h].wo_y, wi, pdf, u[0], u[1]);   // PathTracer.cu:76
+            bool done = (pdf < 0.0001f || len_below_1e4(f));             // PathTracer.cu:77
+            if (!done) {
+                S[h].beta = mul(S[h].beta, divs(scale(f, fabsf(dot(wi, H.normal))), pdf));   // :79
+                Ray nr = spawn_ray(H, wi);                               // :80
+                ro[h] = nr.o; rd[h] = nr.d;
+                if (bounce > 3) {                                        // :82-88
+                    if (u[2] < 0.5f)
+                        done = true;
+                    else
+                        S[h].beta = divs(S[h].beta, 1.0f - 0.5f);
+                }
+            }
+            if (!done && bounce + 1 > A.max_depth) {
+                // next iteration: one draw (:27), a trace whose result nothing reads (bounces >= 1:
+                // no emission, :33), then the break of :64
+                draw[h] += 1u;
+                done = true;
+            }
+            if (done) {
+                finalize_path(v, p, S[h].res);
+                alive[h] = false;
+            }
+            ishit[h] = false;
+        }
+        const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]);
+        if (!(a0 | a1))
+            break;
+        n_bounce += (uint32_t)__popcll(a0) + (uint32_t)__popcll(a1);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+        if (mine[h])
+            v.rng_ctr[pixel_of(h)] = draw[h];
+    if (lane == 0) {
+        if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+        if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
+    }
+}
+
 // Over a deep tree a chunk costs anything from a handful of node tests (rays into empty
 // space) to thousands, so waves draw chunks from a dispenser (`dynamic`); over a shallow
 // one every chunk is cheap, the same-address atomic would be the bottleneck, and waves
@@ -975,6 +1299,21 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
         n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t chunk) { path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
         [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+}
+
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 2) void k_path_area(const PathArgs A, uint32_t *__restrict__ work,
+                                                         uint32_t *__restrict__ work_next, int dynamic)
+{
+    __shared__ uint32_t s_chunk;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
+    ChunkEnv env;
+    env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    run_chunks<CULL>(
+        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
+        [&](uint32_t chunk) { path_chunk_area<CULL>(A, env, chunk, lane); },
+        [&](uint32_t chunk) { path_chunk_area<CULL>(A, env, chunk, lane); });   // (never: no feedback here)
 }
 
 // ------------------------------------------------------------------ depth 0: whole batches of samples
@@ -1717,7 +2056,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const TravArgs T, RayQueue
         uint32_t cost = 0;
         pair_set(w, o, d, inf2, none2, live, T.tv.extent);
         Stamps sp0;
-        traverse<CULL, false>(T, lvloff, w, lane, 0u, nullptr, cost, sp0);
+        traverse<CULL, false, true, true>(T, lvloff, w, lane, 0u, nullptr, cost, sp0);   // triangle lights included (Scene.cu:43-58)
         if (live[0]) { out_t[i[0]] = w.best.x; out_id[i[0]] = w.idx; }
         if (live[1]) { out_t[i[1]] = w.best.y; out_id[i[1]] = w.idy; }
     }
@@ -1819,6 +2158,7 @@ static TravArgs trav_args(const DevView &v)
     T.tv = v.tree; T.tris = v.tris; T.spheres = v.spheres;
     T.n_tris = v.n_tris; T.n_spheres = v.n_spheres;
     T.sorted_planes = v.sorted_planes;
+    T.tlights = v.tlights; T.n_tlights = v.n_tlights;
     return T;
 }
 
@@ -1859,6 +2199,15 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // cooperative form shortens (measured on 1/8 partitions of C3 and C4: 2x and 4x best).
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves * (kBlock / 64);
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
+    if (v.n_tlights > 0) {
+        // scenes with triangle lights: the plain general kernel, without chunk feedback
+        A.fb = ChunkFeedback{};
+        A.occlusion = false;
+        const uint32_t ga = grid_for_chunks(n, max_blocks * 2);
+        if (v.cull) k_path_area<true><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else        k_path_area<false><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        return;
+    }
     if (v.cull) {
         if (!d0) k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else     k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);

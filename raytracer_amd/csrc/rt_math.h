@@ -214,6 +214,24 @@ struct SphereRec {
 struct LightRec { float pos[3]; float illum[3]; int32_t type; int32_t pad; };
 constexpr int kLightPoint = 0, kLightDirectional = 1;
 
+// One TriangleLight (Light/Light.cuh:66-103).  Its hit test (Light.cu:68-92) is Triangle::hit's
+// (Model.cu:97-120) on the light's own vertices, operand for operand, so T holds the same
+// ray-independent sub-expressions: n = cross(p0 - p2, p1 - p2) -- the UNNORMALISED local of
+// Light.cu:72 that also becomes the record's normal (:97) --, dn = dot(p0, n), S = 2 area().
+// T.orig = n_tris + n_quads + k: what the id buffer reports for a hit on light k.
+struct TriLightRec {
+    TriRec T;
+    float normal[3];    // the member: normalize(cross(p1 - p0, p2 - p0)) (Light.cu:39)
+    float area;         // area() (Light.cuh:76-79)
+    float illum[3];
+    int32_t two_side;
+    float e1[3];        // p1 - p0, p2 - p0: the tangent's operands (Light.cu:100)
+    int32_t model;      // ModelRec of the light's own Material: n_models + k (Scene.cu:151-153)
+    float e2[3];
+    int32_t pad;
+};
+static_assert(sizeof(TriLightRec) == 128, "TriLightRec must be 128 bytes");
+
 // Camera after its constructor (Camera/Camera.cu:4-14); pers/raster2world are dead.
 struct CameraRec {
     v3 pos, up, front, right;

@@ -22,6 +22,8 @@ static m4 load_m4(const float *p)
     return m;
 }
 
+static void hit_operands(v3 ta, v3 tb, v3 tc, int orig, TriRec &T);
+
 static void build_tri(const rt_scene_desc *d, int g, TriRec &T, TriCold &C)
 {
     const float *pp = d->tri_pos + 9 * (size_t)g;
@@ -31,6 +33,18 @@ static void build_tri(const rt_scene_desc *d, int g, TriRec &T, TriCold &C)
     v3 pos[3] = {mk3(pp[0], pp[1], pp[2]), mk3(pp[3], pp[4], pp[5]), mk3(pp[6], pp[7], pp[8])};
     // Model.cu:94  ta, tb, tc = transformation(pos[i])
     v3 ta = apply3(M, pos[0]), tb = apply3(M, pos[1]), tc = apply3(M, pos[2]);
+    hit_operands(ta, tb, tc, g, T);
+    std::memcpy(C.n0, nn, 3 * sizeof(float));
+    std::memcpy(C.n1, nn + 3, 3 * sizeof(float));
+    std::memcpy(C.n2, nn + 6, 3 * sizeof(float));
+    C.model = model;
+    C.pad[0] = C.pad[1] = 0;
+}
+
+// The ray-independent operands of Triangle::hit (Model.cu:97-113) -- and of TriangleLight::hit
+// (Light.cu:72-87), which is the same code on the light's vertices -- for world-space vertices.
+static void hit_operands(v3 ta, v3 tb, v3 tc, int orig, TriRec &T)
+{
     // Model.cu:97  norma = cross(ta - tc, tb - tc)
     v3 n = cross(sub(ta, tc), sub(tb, tc));
     // Model.cu:413-420 area(): rpos[i] = transformation(pos[i]) (same values as ta,tb,tc)
@@ -41,7 +55,7 @@ static void build_tri(const rt_scene_desc *d, int g, TriRec &T, TriCold &C)
     T.nx = n.x; T.ny = n.y; T.nz = n.z;
     T.dn = dot(ta, n);          // Model.cu:102 second term
     T.S = 2.0f * area;          // Model.cu:106
-    T.orig = g;
+    T.orig = orig;
     // Largest |cross|^2 (Model.cu:107-109) with which the area test (:113) can pass:
     // one s_i alone above (S + 0.001)(1 + 1e-5) already puts s1+s2+s3-S beyond 0.001.
     {
@@ -51,11 +65,6 @@ static void build_tri(const rt_scene_desc *d, int g, TriRec &T, TriCold &C)
         if (!(qf >= q)) qf = std::nextafter(qf, std::numeric_limits<float>::infinity());
         T.qmax = std::isfinite(q) ? qf : std::numeric_limits<float>::infinity();
     }
-    std::memcpy(C.n0, nn, 3 * sizeof(float));
-    std::memcpy(C.n1, nn + 3, 3 * sizeof(float));
-    std::memcpy(C.n2, nn + 6, 3 * sizeof(float));
-    C.model = model;
-    C.pad[0] = C.pad[1] = 0;
 }
 
 // ------------------------------------------------------------------ culling bounds
@@ -385,6 +394,15 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
             err = "tri_model out of range"; return RT_ERR_INVALID;
         }
     }
+    if (d->n_tri_lights < 0 || (d->n_tri_lights > 0 && (!d->tl_pos || !d->tl_illum || !d->tl_two_side ||
+                                                        !d->tl_mat_type || !d->tl_color))) {
+        err = "triangle-light arrays are NULL or their count negative"; return RT_ERR_INVALID;
+    }
+    for (int k = 0; k < d->n_tri_lights; k++)
+        if (d->tl_mat_type[k] != kMatLambertian) {
+            err = "a triangle light's own material must be LAMBERTIAN (Light.cu:115-125)";
+            return RT_ERR_UNSUPPORTED;
+        }
     for (int m = 0; m < n_models; m++)
         if (d->model_mat_type[m] != kMatLambertian) {
             err = "only LAMBERTIAN materials are on the hot path (GGX/Cook/Oren-Nayar/Fresnel: "
@@ -403,6 +421,29 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
         out.models[m].cas = transpose(inverse(M));        // Model.cu:126
         std::memcpy(out.models[m].color, d->model_color + 3 * (size_t)m, 3 * sizeof(float));
         out.models[m].mat_type = d->model_mat_type[m];
+    }
+
+    // triangle lights and their Materials (ModelRec n_models + k; cas is not read for them)
+    out.tlights.assign((size_t)d->n_tri_lights, TriLightRec{});
+    out.models.resize((size_t)n_models + (size_t)d->n_tri_lights);
+    for (int k = 0; k < d->n_tri_lights; k++) {
+        const float *pp = d->tl_pos + 9 * (size_t)k;
+        const v3 p0 = mk3(pp[0], pp[1], pp[2]), p1 = mk3(pp[3], pp[4], pp[5]), p2 = mk3(pp[6], pp[7], pp[8]);
+        TriLightRec &L = out.tlights[k];
+        hit_operands(p0, p1, p2, d->n_tris + d->n_quads + k, L.T);     // Light.cu:72-81
+        const v3 n = normalize(cross(sub(p1, p0), sub(p2, p0)));       // Light.cu:39
+        L.normal[0] = n.x; L.normal[1] = n.y; L.normal[2] = n.z;
+        L.area = 0.5f * length(cross(sub(p2, p0), sub(p1, p0)));       // Light.cuh:76-79
+        std::memcpy(L.illum, d->tl_illum + 3 * (size_t)k, 3 * sizeof(float));
+        L.two_side = d->tl_two_side[k] != 0;
+        const v3 e1 = sub(p1, p0), e2 = sub(p2, p0);
+        L.e1[0] = e1.x; L.e1[1] = e1.y; L.e1[2] = e1.z;
+        L.e2[0] = e2.x; L.e2[1] = e2.y; L.e2[2] = e2.z;
+        L.model = n_models + k;
+        ModelRec &M = out.models[(size_t)n_models + k];
+        M = ModelRec{};
+        std::memcpy(M.color, d->tl_color + 3 * (size_t)k, 3 * sizeof(float));
+        M.mat_type = d->tl_mat_type[k];
     }
 
     out.spheres.resize((size_t)d->n_quads);

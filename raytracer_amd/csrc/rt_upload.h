@@ -24,6 +24,7 @@ struct HostScene {
     std::vector<ModelRec> models;
     std::vector<SphereRec> spheres;
     std::vector<LightRec> lights;
+    std::vector<TriLightRec> tlights;    // triangle lights (their Materials: models[n_models + k])
 };
 
 // Scene::initializeScene (Scene/Scene.cu:126-202) on the host: validates the flat

@@ -89,7 +89,9 @@ class SceneDesc(C.Structure):
                 ("mesh_first", _IP), ("mesh_count", _IP), ("model_xf", _FP),
                 ("model_mat_type", _IP), ("model_color", _FP), ("quad_coeff", _FP),
                 ("quad_type", _IP), ("n_point_lights", C.c_int32), ("pl_pos", _FP),
-                ("pl_illum", _FP), ("n_dir_lights", C.c_int32), ("dl_dir", _FP), ("dl_illum", _FP)]
+                ("pl_illum", _FP), ("n_dir_lights", C.c_int32), ("dl_dir", _FP), ("dl_illum", _FP),
+                ("n_tri_lights", C.c_int32), ("tl_pos", _FP), ("tl_illum", _FP), ("tl_two_side", _IP),
+                ("tl_mat_type", _IP), ("tl_color", _FP)]
 
 
 @dataclass
@@ -110,6 +112,12 @@ class SceneData:
     pl_illum: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     dl_dir: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     dl_illum: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    # TriangleLight(posa, posb, posc, light_color, two) + its own Material (Light.cuh:71, Scene.cu:151-153)
+    tl_pos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3, 3), np.float32))
+    tl_illum: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    tl_two_side: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    tl_mat_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
+    tl_color: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
 
     @property
     def n_tris(self):
@@ -133,8 +141,13 @@ class SceneData:
 
     @property
     def n_lights(self):
-        """Delta lights: point lights, then directional ones (Scene.cu:83-102 order)."""
-        return int(self.pl_pos.shape[0]) + int(np.asarray(self.dl_dir).reshape(-1, 3).shape[0])
+        """Lights in Scene::sampleAllLight order (Scene.cu:83-114): point, directional, triangle."""
+        return int(self.pl_pos.shape[0]) + int(np.asarray(self.dl_dir).reshape(-1, 3).shape[0]) + \
+            self.n_tri_lights
+
+    @property
+    def n_tri_lights(self):
+        return int(np.asarray(self.tl_pos).reshape(-1, 3, 3).shape[0])
 
     def normalise(self):
         n = self.tri_pos.shape[0] if self.tri_pos.ndim == 3 else np.asarray(self.tri_pos).size // 9
@@ -153,6 +166,12 @@ class SceneData:
         self.pl_illum = _f32(self.pl_illum, (-1, 3))
         self.dl_dir = _f32(self.dl_dir, (-1, 3))
         self.dl_illum = _f32(self.dl_illum, (-1, 3))
+        self.tl_pos = _f32(self.tl_pos, (-1, 3, 3))
+        nl = self.tl_pos.shape[0]
+        self.tl_illum = _f32(self.tl_illum, (nl, 3))
+        self.tl_two_side = _i32(self.tl_two_side, (nl,))
+        self.tl_mat_type = _i32(self.tl_mat_type, (nl,))
+        self.tl_color = _f32(self.tl_color, (nl, 3))
         assert self.pl_pos.shape == self.pl_illum.shape
         assert self.dl_dir.shape == self.dl_illum.shape
         assert self.quad_type.shape[0] == self.quad_coeff.shape[0]
@@ -176,6 +195,9 @@ class SceneData:
         d.pl_pos, d.pl_illum = fp(self.pl_pos), fp(self.pl_illum)
         d.n_dir_lights = int(self.dl_dir.shape[0])
         d.dl_dir, d.dl_illum = fp(self.dl_dir), fp(self.dl_illum)
+        d.n_tri_lights = self.n_tri_lights
+        d.tl_pos, d.tl_illum, d.tl_color = fp(self.tl_pos), fp(self.tl_illum), fp(self.tl_color)
+        d.tl_two_side, d.tl_mat_type = ip(self.tl_two_side), ip(self.tl_mat_type)
         return d
 
 
@@ -189,6 +211,7 @@ class SceneBuilder:
         self._quads = []     # (coeff, type, xf, color)
         self._lights = []
         self._dir_lights = []
+        self._tri_lights = []
 
     def add_triangle(self, pos, nrm, xf=None, color=(0.7, 0.7, 0.7)):
         self._tris.append((_f32(pos, (3, 3)), _f32(nrm, (3, 3)),
@@ -214,6 +237,12 @@ class SceneBuilder:
     def add_directional_light(self, direction, illum):
         """DirectionalLight(direction, color) (Light/Light.cuh:57)."""
         self._dir_lights.append((direction, illum))
+        return self
+
+    def add_triangle_light(self, pos, illum, two_side=False, color=(1.0, 1.0, 1.0)):
+        """TriangleLight(posa, posb, posc, light_color, two) with a Lambertian material of its
+        own (Light/Light.cuh:71, Light.cu:112-135; kernel.cu:281-283)."""
+        self._tri_lights.append((_f32(pos, (3, 3)), illum, bool(two_side), color))
         return self
 
     def build(self) -> SceneData:
@@ -245,4 +274,9 @@ class SceneBuilder:
         s.pl_illum = np.array([l[1] for l in self._lights], np.float32).reshape(-1, 3)
         s.dl_dir = np.array([l[0] for l in self._dir_lights], np.float32).reshape(-1, 3)
         s.dl_illum = np.array([l[1] for l in self._dir_lights], np.float32).reshape(-1, 3)
+        s.tl_pos = np.array([l[0] for l in self._tri_lights], np.float32).reshape(-1, 3, 3)
+        s.tl_illum = np.array([l[1] for l in self._tri_lights], np.float32).reshape(-1, 3)
+        s.tl_two_side = np.array([l[2] for l in self._tri_lights], np.int32)
+        s.tl_mat_type = np.full(len(self._tri_lights), MAT_LAMBERTIAN, np.int32)
+        s.tl_color = np.array([l[3] for l in self._tri_lights], np.float32).reshape(-1, 3)
         return s.normalise()

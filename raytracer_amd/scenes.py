@@ -329,4 +329,36 @@ def sun_test_scene(seed=7):
     return scene.normalise(), rng
 
 
+def demo_scene():
+    """The reference's own demo scene (kernel.cu:268-313) without its environment light (out of
+    scope): two spheres -- the small one and the huge 'ground' one -- lit by one two-sided
+    TriangleLight whose own Material is white Lambertian; light_size = {0, 0, 1, 0}."""
+    b = SceneBuilder()
+    b.add_sphere(0.33, translation(0.0, 0.0, -8.0), color=(0.7, 0.0, 0.0))         # q,  Material m
+    b.add_sphere(0.01, translation(0.0, -103.0, -8.0), color=(0.9, 0.0, 0.0))      # s,  Material c
+    b.add_triangle_light([(0.0, 10.3, -2.0), (2.0, 0.7, -3.0), (0.0, 0.0, -3.0)], (31.0, 31.0, 31.0),
+                         two_side=True, color=(1.0, 1.0, 1.0))                    # trl, Material cs
+    return b.build()
+
+
+def area_test_scene(seed=7):
+    """mixed_test_scene lit by every supported light type at once: two point lights, one
+    directional light, a one-sided triangle light above the scene (facing down) and a two-sided
+    one standing among the models, so that lights block each other's shadow rays, the camera
+    sees both, and paths bounce off their surfaces."""
+    scene, rng = mixed_test_scene(seed)
+    scene.pl_pos = scene.pl_pos[:2].copy()
+    scene.pl_illum = (scene.pl_illum[:2] * 0.25).copy()
+    scene.dl_dir = np.float32([[0.6, -0.35, -0.7]])
+    scene.dl_illum = np.float32([[0.5, 0.45, 0.4]])
+    scene.tl_pos = np.float32([
+        [(-160.0, 260.0, -300.0), (-160.0, 250.0, -520.0), (140.0, 255.0, -400.0)],   # normal points down
+        [(150.0, -60.0, -330.0), (190.0, 90.0, -350.0), (120.0, 60.0, -300.0)]])
+    scene.tl_illum = np.float32([[260.0, 240.0, 200.0], [60.0, 90.0, 140.0]])
+    scene.tl_two_side = np.int32([0, 1])
+    scene.tl_mat_type = np.int32([1, 1])
+    scene.tl_color = np.float32([[0.8, 0.8, 0.8], [0.5, 0.6, 0.9]])
+    return scene.normalise(), rng
+
+
 CONFIGS = {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}

@@ -171,3 +171,46 @@ def test_squared_length_thresholds():
         assert np.sqrt(below, dtype=np.float32) < c and not (np.sqrt(t, dtype=np.float32) < c)
         y = np.linspace(0.0, 4.0 * thr, 200001).astype(np.float32)
         assert np.array_equal(np.sqrt(y, dtype=np.float32) < c, y < t)
+
+
+def test_triangle_light_emission_and_sidedness():
+    """TriangleLight (Light/Light.cu:35-105, PathTracer.cu:33-52): a camera ray that lands on the
+    light picks up L(-dir) -- illum from either side of a two-sided light, from the side its
+    normal = normalize(cross(p1 - p0, p2 - p0)) points to of a one-sided one -- plus whatever
+    sampleAllLight finds at that surface point; the hit reports id n_tris + n_quads + k."""
+    from raytracer_amd.scene import SceneBuilder
+    cam = CameraArgs.for_image(32, 24)
+    tri = [(-30.0, -30.0, -8.0), (30.0, -30.0, -8.0), (0.0, 40.0, -8.0)]   # normal +z: faces the camera
+    for two_side, verts, lit in [(False, tri, True), (False, tri[::-1], False), (True, tri[::-1], True)]:
+        b = SceneBuilder()
+        b.add_triangle_light(verts, (5.0, 6.0, 7.0), two_side=two_side, color=(0.5, 0.5, 0.5))
+        r = orc.render(b.build(), cam, 32, 24, spp=1, max_depth=0, crop=(14, 10, 18, 14))
+        assert np.all(r["prim_id"] == 0)                      # no models: the light is id 0
+        want = (5.0, 6.0, 7.0) if lit else (0.0, 0.0, 0.0)
+        # a lone flat light does not light itself: the sampled point lies in the surface's own plane
+        np.testing.assert_allclose(r["rgba"][..., :3], np.broadcast_to(np.float32(want), r["rgba"][..., :3].shape),
+                                   rtol=1e-6)
+
+
+def test_triangle_light_blocks_and_is_sampled():
+    """A floor under a one-sided light facing down is lit through the MIS branch (Scene.cu:242-284);
+    turned upwards the same light leaves it black, and a second light's triangle in between casts a
+    shadow like any model (Scene.cu:227: lightidx != idx)."""
+    from raytracer_amd.scene import SceneBuilder, identity
+    cam = CameraArgs.for_image(32, 24, pos=(0.0, 2.0, 0.0), lookat=(0.0, -1.0, -6.0))
+    floor = ([(-12.0, -3.0, 2.0), (12.0, -3.0, 2.0), (0.0, -3.0, -30.0)], [(0.0, 1.0, 0.0)] * 3)
+    down = [(-2.0, 6.0, -8.0), (0.0, 6.0, -11.0), (2.0, 6.0, -8.0)]         # cross(p1-p0, p2-p0) = -y
+    def mean_floor(lights):
+        b = SceneBuilder()
+        b.add_triangle(floor[0], floor[1], identity(), (0.7, 0.7, 0.7))
+        for verts, two in lights:
+            b.add_triangle_light(verts, (40.0, 40.0, 40.0), two_side=two, color=(0.5, 0.5, 0.5))
+        r = orc.render(b.build(), cam, 32, 24, spp=8, max_depth=0, crop=(8, 0, 24, 8))                 # (row 0 is the bottom of the image)
+        floor_px = r["prim_id"] == 0
+        assert floor_px.sum() > 100
+        return float(r["rgba"][..., 0][floor_px].mean())
+    lit = mean_floor([(down, False)])
+    assert lit > 0.05
+    assert mean_floor([(down[::-1], False)]) == 0.0                          # faces up: L = BLACK
+    blocker = [(-12.0, 4.0, 2.0), (12.0, 4.0, 2.0), (0.0, 4.0, -30.0)]       # one-sided, faces up, below the light
+    assert mean_floor([(down, False), (blocker, False)]) < 0.02 * lit

@@ -722,3 +722,68 @@ def test_full_size_c5_render(gpu_ctx_factory, c5_full):
     for k in ("rgba", "t", "prim_id"):
         assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
     assert shadow[0] == shadow[1] and shadow[0] > 0
+
+
+# ----------------------------------------------------------------------------- triangle lights (N3)
+def test_triangle_lights_full_frames(gpu_ctx_factory):
+    """Scenes with TriangleLights (hit-able, emissive, sampled with MIS: Light.cu:35-105,
+    PathTracer.cu:33-52, Scene.cu:43-64,242-284) through k_path_area: whole frames against the
+    oracle with ray counts, at depth 0 and with bounces off the lights' own surfaces; the tree
+    and the scan agree bit for bit; rendering in two calls equals one."""
+    scene, _ = scenes.area_test_scene()
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    for spp, depth in [(1, 0), (3, 4)]:
+        got, ref, st = render_both(gpu_ctx_factory, scene, cam, 96, 64, spp, depth)
+        check_images(got, ref, st)
+        assert st.batch_launches == 0
+        n_prims = scene.n_tris + scene.n_quads
+        assert (got["prim_id"] >= n_prims).sum() > 50         # the camera sees a light
+    ctx = gpu_ctx_factory(96, 64)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    ctx.set_culling(0)
+    ctx.render(2, 4)
+    ctx.render(1, 4)
+    scan = ctx.read_framebuffer()
+    assert np.array_equal(scan["rgba"].view(np.uint32), got["rgba"].view(np.uint32))
+    assert np.array_equal(scan["prim_id"], got["prim_id"])
+
+
+def test_reference_demo_scene(gpu_ctx_factory):
+    """The reference's own demo scene (kernel.cu:268-313: two spheres under a two-sided triangle
+    light, camera of kernel.cu:228-229) without its environment light, 320x240, 4 spp, depth 12."""
+    scene = scenes.demo_scene()
+    cam = CameraArgs.for_image(320, 240)
+    got, ref, st = render_both(gpu_ctx_factory, scene, cam, 320, 240, 4, 12)
+    check_images(got, ref, st)
+    assert (got["prim_id"] == 2).sum() > 1000 and st.bounce_rays > 0
+
+
+def test_scene_hit_with_triangle_lights(gpu_ctx_factory):
+    """Scene::hit tests the triangle lights after every model (Scene.cu:43-58)."""
+    scene, rng = scenes.area_test_scene()
+    ctx = gpu_ctx_factory(16, 16)
+    ctx.upload_scene(scene)
+    n = 20000
+    org = rng.uniform(-50, 50, (n, 3)).astype(np.float32)
+    org[:, 2] += 40.0
+    tgt = rng.uniform([-350, -150, -900], [350, 300, -150], (n, 3)).astype(np.float32)
+    tgt[: n // 4] = rng.uniform([100, -70, -360], [200, 100, -290], (n // 4, 3))     # at the standing light
+    d = tgt - org
+    rt, rpid, rhit = orc.scene_hit(scene, org, d)
+    for cull in (1, 0):
+        ctx.set_culling(cull)
+        t, pid, hit = ctx.scene_hit(org, d)
+        assert np.array_equal(pid, rpid)
+        assert np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+        assert np.array_equal(hit, rhit)
+    assert (pid >= scene.n_tris + scene.n_quads).sum() > 200
+
+
+def test_triangle_light_material_must_be_lambertian(gpu_ctx_factory):
+    scene = scenes.demo_scene()
+    scene.tl_mat_type = np.int32([3])
+    ctx = gpu_ctx_factory(16, 16)
+    with pytest.raises(abi.RtError) as e:
+        ctx.upload_scene(scene)
+    assert e.value.code == abi.RT_ERR_UNSUPPORTED

@@ -58,8 +58,9 @@ typedef struct rt_scene_desc {
     const int32_t *mesh_first;     /* [n_meshes] first triangle of Mesh j         */
     const int32_t *mesh_count;     /* [n_meshes] Mesh::number (Model.cuh:97)      */
     const float *model_xf;         /* [n_models][16] Model::transformation, row-major (Model.cuh:57) */
-    const int32_t *model_mat_type; /* [n_models] material::MATERIAL_TYPE; LAMBERTIAN = 1 only */
-    const float *model_color;      /* [n_models][3] Lambertian::color (material.cuh:39) */
+    const int32_t *model_mat_type; /* [n_models] material::MATERIAL_TYPE (Object.cuh:13-21): LAMBERTIAN 1,
+                                      FRESNEL 7, Cook 9, GGX 17, Oren_Nayar 25 */
+    const float *model_color;      /* [n_models][3] the BRDF's color (material.cuh:39,62,81,103,162) */
     const float *quad_coeff;       /* [n_quads][3] Quadratic::coefficient (Model.cuh:116) */
     const int32_t *quad_type;      /* [n_quads] quadraticType, Sphere = 0 (Model.cuh:100-103) */
     int32_t n_point_lights;        /* light_size[0]                               */
@@ -76,6 +77,9 @@ typedef struct rt_scene_desc {
     const int32_t *tl_mat_type;    /* [n_tri_lights] material_type[n_models + k]: the light's own
                                       Material (Scene.cu:151-153); LAMBERTIAN only (Light.cu:115-125) */
     const float *tl_color;         /* [n_tri_lights][3] its Lambertian::color     */
+    const float *model_param;      /* [n_models][2] (roughness, eta): the second constructor argument of
+                                      GGX / Cook_Torrance (material.cuh:48,88) and of Fresnel (:112);
+                                      may be NULL when every model is LAMBERTIAN or Oren_Nayar */
 } rt_scene_desc;
 
 /* Camera(pos, lookat, fov, near, far, int2 res, up)          (Camera/Camera.cuh:11).

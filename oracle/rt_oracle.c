@@ -150,6 +150,11 @@ static inline f3 ray_pos(const ray_t *r, float t) { return add3(r->o, scale3(r->
 #define ORC_PI_OVER4 0.78539816339744830961f /* material.cu:7 */
 #define ORC_PI_OVER2 1.57079632679489661923f /* material.cu:8 */
 #define ORC_MAT_LAMBERTIAN 1          /* Material/Object.cuh:15 */
+#define ORC_MAT_FRESNEL 7             /* Object.cuh:16 */
+#define ORC_MAT_COOK 9                /* Object.cuh:17 */
+#define ORC_MAT_OREN_NAYAR 25         /* Object.cuh:18 */
+#define ORC_MAT_GGX 17                /* Object.cuh:19 */
+#define ORC_PI_D 3.14159265358979323846   /* M_PI */
 #define ORC_MAT_SPECULAR_BIT 4        /* Material/Object.cuh:10 */
 
 /* ---------------------------------------------------------------- record */
@@ -540,7 +545,49 @@ static f3 sample_hemi(f2 sample)
     return mk3(d.x, z, d.y);
 }
 
-/* Material/material.cu:52-57 Lambertian::f; c = rec.color, brdf = Lambertian::color */
+/* Transcendentals of the non-Lambertian BRDFs (material.cu:84-254, material.cuh:7-13,108-164):
+ * acosf / sinf / cosf / logf / powf are whatever libm the reference is built against -- not
+ * bit-specified.  The build fixes each as the float rounding of the double-precision function, on
+ * the CPU here and on the GPU alike (glibc's and the device library's double results differ, if at
+ * all, far below a float ulp). */
+static float m_acosf(float x) { return (float)acos((double)x); }
+static float m_sinf(float x) { return (float)sin((double)x); }
+static float m_cosf(float x) { return (float)cos((double)x); }
+static float m_logf(float x) { return (float)log((double)x); }
+static float m_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+
+/* material.cuh:7-13 rough2alpha */
+float orc_rough2alpha(float rough)
+{
+    rough = fmaxf(rough, 1e-3f);
+    float x = m_logf(rough);
+    return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x +
+           0.000640711f * x * x * x * x;
+}
+
+/* The BRDF object behind a Material, as its constructor leaves it (material.cuh:32,48,74,88,112). */
+typedef struct { int type; f3 color; float a2, m, eta; } brdf_t;
+static f3 model_color(const orc_scene *s, int model)
+{
+    int n_models = s->n_tri_models + s->n_meshes + s->n_quads;
+    const float *c = model < n_models ? s->model_color + 3 * (size_t)model
+                                      : s->tl_color + 3 * (size_t)(model - n_models);
+    return mk3(c[0], c[1], c[2]);
+}
+static brdf_t brdf_of(const orc_scene *s, int model, int type)
+{
+    int n_models = s->n_tri_models + s->n_meshes + s->n_quads;
+    brdf_t b;
+    b.type = type;
+    b.color = model_color(s, model);
+    float rough = (model < n_models && s->model_param) ? s->model_param[2 * (size_t)model] : 0.0f;
+    b.eta = (model < n_models && s->model_param) ? s->model_param[2 * (size_t)model + 1] : 0.0f;
+    b.m = orc_rough2alpha(rough);                       /* material.cuh:88 */
+    b.a2 = b.m * b.m;                                   /* material.cuh:48,88 */
+    return b;
+}
+
+/* Material/material.cu:52-57 Lambertian::f */
 static f3 lambert_f(f3 wo, f3 wi, f3 c, f3 brdf)
 {
     if (c.x < 0.0f)
@@ -554,38 +601,212 @@ static float lambert_pdf(f3 wo, f3 wi)
     return wi.y > +0.0f ? wi.y * ORC_INV_PI : 0.0f;
 }
 
-static f3 model_color(const orc_scene *s, int model)
+/* material.cu:85-90 GGX::SchlickFresnel = material.cuh:96-101 Cook_Torrance::F */
+static f3 schlick(f3 r0, float r)
 {
-    int n_models = s->n_tri_models + s->n_meshes + s->n_quads;
-    const float *c = model < n_models ? s->model_color + 3 * (size_t)model
-                                      : s->tl_color + 3 * (size_t)(model - n_models);
-    return mk3(c[0], c[1], c[2]);
+    float t = (1.0f - r);
+    f3 a = mk3(1.0f - r0.x, 1.0f - r0.y, 1.0f - r0.z);
+    a = scale3(scale3(scale3(a, t * t), t * t), t);
+    return add3(r0, a);
+}
+/* material.cu:92-98 GGX::G = :192-198 Cook_Torrance::G */
+static float smith_g(float a2, f3 wi, f3 wo)
+{
+    float A = wo.y * sqrtf(a2 + (1.0f - a2) * wi.y * wi.y);
+    float B = wi.y * sqrtf(a2 + (1.0f - a2) * wo.y * wo.y);
+    return 2.0f * wo.y * wi.y / (A + B);
+}
+/* material.cu:100-103 GGX::D (M_PI makes the expression double) */
+static float ggx_d(float a2, f3 wh)
+{
+    float k = wh.y * wh.y * (a2 - 1) + 1;
+    return (float)((double)a2 / (ORC_PI_D * (double)k * (double)k));
+}
+/* material.cu:105-114 */
+static f3 ggx_f(const brdf_t *b, f3 wo, f3 wi, f3 c)
+{
+    if (c.x < 0.0f)
+        c = b->color;
+    float dotwin_won = fmaxf(0.0001f, fabsf(4.0f * wi.y * wo.y));
+    f3 wh = normalize3(add3(wo, wi));
+    return div3s(scale3(scale3(schlick(c, dot3(wi, wh)), ggx_d(b->a2, wh)), smith_g(b->a2, wi, wo)),
+                 dotwin_won);
+}
+/* material.cu:132-137 */
+static float ggx_pdf(const brdf_t *b, f3 wo, f3 wi)
+{
+    f3 wh = normalize3(add3(wo, wi));
+    return wi.y > 0.0f && dot3(wi, wh) > 0.0f ? ggx_d(b->a2, wh) * wh.y * 0.25f / wo.y : 0.0f;
+}
+/* material.cu:116-130 */
+static f3 ggx_sample_f(const brdf_t *b, f3 wo, f3 *wi, float *pdf, f2 sample, f3 c)
+{
+    if (c.x < 0.0f)
+        c = b->color;
+    float theta = m_acosf(sqrtf((1.0f - sample.x) / ((b->a2 - 1.0f) * sample.x + 1.0f)));
+    float phi = (float)((double)sample.y * ORC_PI_D * (double)2.0f);
+    f3 wh = mk3(m_sinf(theta) * m_sinf(phi), m_cosf(theta), m_cosf(phi) * m_sinf(theta));
+    *wi = sub3(scale3(wh, 2.0f * dot3(wo, wh)), wo);
+    *pdf = ggx_pdf(b, wo, *wi);
+    return ggx_f(b, wo, *wi, c);
 }
 
-/* Material/Object.cu:3-32 Material::f via IntersectionRecord.cuh:44-47 (Lambertian only;
- * any other type returns BLACK here: out of scope). */
+static float clampf(float v, float lo, float hi) { return v < lo ? lo : hi < v ? hi : v; }   /* material.cu:11-21 */
+/* material.cu:140-170 Oren_Nayar::f (sigma = 0.5; the double literals make A, B, TanBeta double
+ * expressions narrowed to float; SinPhiO divides by SinThetaI as written, :154) */
+static f3 oren_f(const brdf_t *b, f3 wo, f3 wi, f3 c)
+{
+    if (c.x < 0.0f)
+        c = b->color;
+    float sigma = 0.5;
+    float A = (float)(1 - 0.5 * sigma * sigma / (sigma * sigma + 0.33));
+    float B = (float)(0.45 * sigma * sigma / (sigma * sigma + 0.09));
+    float CosThetaI = wi.y, CosThetaO = wo.y;
+    float SinThetaI = sqrtf(1 - CosThetaI * CosThetaI);
+    float SinThetaO = sqrtf(1 - CosThetaO * CosThetaO);
+    float CosPhiI = (SinThetaI == 0) ? 1 : clampf(wi.x / SinThetaI, -1, 1);
+    float CosPhiO = (SinThetaO == 0) ? 0 : clampf(wo.x / SinThetaO, -1, 1);
+    float SinPhiI = (SinThetaI == 0) ? 1 : clampf(wi.z / SinThetaI, -1, 1);
+    float SinPhiO = (SinThetaO == 0) ? 0 : clampf(wo.z / SinThetaI, -1, 1);
+    float dCos = CosPhiI * CosPhiO + SinPhiI * SinPhiO;
+    float maxCos = (dCos > 0) ? dCos : 0;
+    float SinAlpha, TanBeta;
+    if (CosThetaI * CosThetaI > CosThetaO * CosThetaO) {
+        SinAlpha = SinThetaO;
+        TanBeta = (float)(SinThetaI * 1.0 / ((CosThetaI > 0) ? CosThetaI : (-1 * CosThetaI)));
+    } else {
+        SinAlpha = SinThetaI;
+        TanBeta = (float)(SinThetaI * 1.0 / ((CosThetaO > 0) ? CosThetaO : (-1 * CosThetaO)));
+    }
+    return (wo.y > 0.0f && wi.y > 0.0f) ? scale3(scale3(c, ORC_INV_PI), A + B * maxCos * SinAlpha * TanBeta)
+                                        : mk3(0.0f, 0.0f, 0.0f);
+}
+
+/* material.cu:241-245 Cook_Torrance::D: pow(float, int) promotes to double (C++11), pow(float,
+ * float) is powf; ex = 2.718281828f (:9) */
+static float cook_d(const brdf_t *b, f3 wo)
+{
+    float m = b->m;
+    float c = (float)(1.0 / ((double)(m * m) * pow((double)wo.y, 4.0)));
+    return c * m_powf(2.718281828f, -(m_acosf(wo.y) * m_acosf(wo.y)) / (m * m));
+}
+/* material.cu:200-208 */
+static f3 cook_f(const brdf_t *b, f3 wo, f3 wi, f3 c)
+{
+    if (c.x < 0.0f)
+        c = b->color;
+    float dotwin_won = fmaxf(0.0001f, fabsf(4.0f * wi.y * wo.y));
+    f3 wh = normalize3(add3(wo, wi));
+    return div3s(scale3(scale3(schlick(c, dot3(wi, wh)), cook_d(b, wh)), smith_g(b->a2, wi, wo)),
+                 dotwin_won);
+}
+/* material.cu:246-254 */
+static float cook_pdf(const brdf_t *b, f3 wo, f3 wi)
+{
+    if (!(wo.y * wi.y > 0))                                         /* SameHemisphere, :23-25 */
+        return 0;
+    f3 wh = normalize3(add3(wo, wi));
+    if (dot3(wo, wh) == 0.0f)
+        return 0.0f;
+    return cook_d(b, wh) / (4 * dot3(wo, wh));
+}
+/* material.cu:209-234.  The half vector sampled at :216-227 is overwritten at :229 by
+ * normalize(wo + *wi), with *wi the caller's variable as it comes in (hazard H9: uninitialised in
+ * Scene.cu:253 and at the first bounce, PathTracer.cu:18 -- restated as (0, 0, 0) --, the previous
+ * bounce's WORLD-space wi afterwards). */
+static f3 cook_sample_f(const brdf_t *b, f3 wo, f3 *wi, float *pdf, f2 sample, f3 c)
+{
+    if (c.x < 0.0f)
+        c = b->color;
+    (void)sample;       /* :216-227 compute a wh nothing reads */
+    f3 wh = normalize3(add3(wo, *wi));                              /* :229 */
+    *wi = sub3(scale3(wh, 2.0f * dot3(wo, wh)), wo);                /* :230 */
+    *pdf = cook_pdf(b, wo, *wi);
+    return cook_f(b, wo, *wi, c);
+}
+
+/* material.cuh:118-152 Fresnel::sample_f */
+static f3 fresnel_sample_f(const brdf_t *b, f3 wo, f3 *wi, float *pdf, f2 sample, f3 c)
+{
+    if (c.x < 0.0f)
+        c = b->color;
+    int entering = wo.y > 0.0f;
+    float n1 = 1.0f, n2 = b->eta;
+    float R = (n1 - n2) / (n1 + n2);
+    R *= R;
+    float t = fabsf(wo.y);
+    float F = R + (t * t) * (t * t) * t * (1.0f - R);
+    if (sample.x < F) {
+        *pdf = F;
+        *wi = mk3(-wo.x, wo.y, -wo.z);
+        return div3s(scale3(c, F), fmaxf(fabsf(wi->y), 0.0000001f));
+    } else {
+        *pdf = 1 - F;
+        float etas;
+        float sin2theta = fmaxf(0.001f, 1.0f - wo.y * wo.y);
+        if (!entering)
+            etas = 1.0f / b->eta;
+        else
+            etas = b->eta;
+        if (sin2theta * etas * etas >= 1.0f)
+            return mk3(0.0f, 0.0f, 0.0f);
+        float costhetaT = sqrtf(1.0f - etas * etas * sin2theta);
+        *wi = add3(scale3(wo, -etas), scale3(mk3(0.0f, 1.0f, 0.0f), etas * wo.y - costhetaT));
+        *wi = normalize3(*wi);
+        return div3s(scale3(c, 1.0f - F), fmaxf(fabsf(wi->y), 0.0000001f));
+    }
+}
+
+/* Material/Object.cu:3-32 Material::f via IntersectionRecord.cuh:44-47 */
 static f3 rec_f(const orc_scene *s, const rec_t *rec, f3 wo, f3 wi)
 {
-    if (rec->material_type != ORC_MAT_LAMBERTIAN)
-        return mk3(0.0f, 0.0f, 0.0f);
-    return lambert_f(world2local(rec->normal, rec->tangent, wo),
-                     world2local(rec->normal, rec->tangent, wi), rec->color,
-                     model_color(s, rec->material));
+    brdf_t b = brdf_of(s, rec->material, rec->material_type);
+    f3 lo = world2local(rec->normal, rec->tangent, wo), li = world2local(rec->normal, rec->tangent, wi);
+    switch (rec->material_type) {
+    case ORC_MAT_LAMBERTIAN: return lambert_f(lo, li, rec->color, b.color);
+    case ORC_MAT_GGX: return ggx_f(&b, lo, li, rec->color);
+    case ORC_MAT_COOK: return cook_f(&b, lo, li, rec->color);
+    case ORC_MAT_OREN_NAYAR: return oren_f(&b, lo, li, rec->color);
+    default: return mk3(0.0f, 0.0f, 0.0f);                          /* FRESNEL: BLACK (:11-14) */
+    }
 }
-/* Material/Object.cu:34-72 Material::sample_f -> material.cu:59-71 */
+/* Material/Object.cu:34-72 Material::sample_f.  *wi is in/out (H9, cook_sample_f). */
 static f3 rec_sample_f(const orc_scene *s, const rec_t *rec, f3 wo, f3 *wi, float *pdf, f2 sample)
 {
+    brdf_t b = brdf_of(s, rec->material, rec->material_type);
     f3 rwo = world2local(rec->normal, rec->tangent, wo);
     f3 res = mk3(0.0f, 0.0f, 0.0f);
-    *wi = mk3(0.0f, 0.0f, 0.0f);
-    *pdf = 0.0f;
-    if (rec->material_type == ORC_MAT_LAMBERTIAN) {
+    switch (rec->material_type) {
+    case ORC_MAT_LAMBERTIAN:
         *wi = sample_hemi(sample);
         *pdf = lambert_pdf(rwo, *wi);
-        res = lambert_f(rwo, *wi, rec->color, model_color(s, rec->material));
+        res = lambert_f(rwo, *wi, rec->color, b.color);
+        break;
+    case ORC_MAT_FRESNEL: res = fresnel_sample_f(&b, rwo, wi, pdf, sample, rec->color); break;
+    case ORC_MAT_GGX: res = ggx_sample_f(&b, rwo, wi, pdf, sample, rec->color); break;
+    case ORC_MAT_COOK: res = cook_sample_f(&b, rwo, wi, pdf, sample, rec->color); break;
+    case ORC_MAT_OREN_NAYAR:                                        /* material.cu:171-188 */
+        *wi = sample_hemi(sample);
+        *pdf = lambert_pdf(rwo, *wi);
+        res = oren_f(&b, rwo, *wi, rec->color);
+        break;
+    default: break;                                                 /* (*wi, *pdf untouched) */
     }
     *wi = local2world(rec->normal, rec->tangent, *wi);
     return res;
+}
+/* Material/Object.cu:74-104 Material::PDF */
+static float rec_pdf(const orc_scene *s, const rec_t *rec, f3 wo, f3 wi)
+{
+    brdf_t b = brdf_of(s, rec->material, rec->material_type);
+    f3 rwo = world2local(rec->normal, rec->tangent, wo), rwi = world2local(rec->normal, rec->tangent, wi);
+    switch (rec->material_type) {
+    case ORC_MAT_LAMBERTIAN: return lambert_pdf(rwo, rwi);
+    case ORC_MAT_GGX: return ggx_pdf(&b, rwo, rwi);
+    case ORC_MAT_COOK: return cook_pdf(&b, rwo, rwi);
+    case ORC_MAT_OREN_NAYAR: return lambert_pdf(rwo, rwi);          /* material.cu:185-188 */
+    default: return 0.0f;                                           /* FRESNEL (:83-86) */
+    }
 }
 
 /* ---------------------------------------------------------------- lights */
@@ -643,15 +864,6 @@ static f3 eval_direct_delta(const orc_scene *s, int type, int j, rec_t rec, orc_
     return res;
 }
 
-/* Material/Object.cu:74-104 Material::PDF -> material.cu:79-82 */
-static float rec_pdf(const rec_t *rec, f3 wo, f3 wi)
-{
-    if (rec->material_type != ORC_MAT_LAMBERTIAN)
-        return 0.0f;
-    return lambert_pdf(world2local(rec->normal, rec->tangent, wo),
-                       world2local(rec->normal, rec->tangent, wi));
-}
-
 #define POWER_HEURISTIC(x, y) ((x) * (x) / ((x) * (x) + (y) * (y)))   /* Scene/Scene.cuh:5-7 */
 
 /* Scene/Scene.cu:205-287 evaluateDirectLight for triangle light k (isDelta = false, idx = k),
@@ -688,13 +900,13 @@ static f3 eval_direct_area(const orc_scene *s, int k, rec_t rec, f2 sample_light
     if (rec.pdf_light < 0.001f)                                     /* :233 */
         return mk3(0.0f, 0.0f, 0.0f);
     if (!is_black(f) && !blocked && !is_black(color)) {             /* :236 */
-        rec.pdf_surface = rec_pdf(&rec, neg3(rec.wo.d), r.d);       /* :244 */
+        rec.pdf_surface = rec_pdf(s, &rec, neg3(rec.wo.d), r.d);       /* :244 */
         float weight = POWER_HEURISTIC(rec.pdf_light, rec.pdf_surface);   /* :245 */
         weight /= rec.pdf_light;                                    /* :246 */
         color = scale3(mul3(color, f), weight);                     /* :247 */
         res = color;
     }
-    f3 wi;
+    f3 wi = mk3(0.0f, 0.0f, 0.0f);                                  /* :253 uninitialised: H9 */
     float weight = 1.0f;
     f = rec_sample_f(s, &rec, neg3(rec.wo.d), &wi, &rec.pdf_surface, sample_brdf);   /* :258 */
     f = scale3(f, fabsf(dot3(rec.normal, wi)));                     /* :259 */
@@ -818,9 +1030,9 @@ static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_
                       float *first_t, int *first_prim)
 {
     rec_t rec;
-    int ishit;
+    int ishit, specular_bounce = 0;
     float pdf;
-    f3 le, wi;
+    f3 le, wi = mk3(0.0f, 0.0f, 0.0f);                              /* :18 uninitialised: H9 */
     f3 beta = mk3(1.0f, 1.0f, 1.0f);
     f3 res = mk3(0.0f, 0.0f, 0.0f);
     float tmp[4];
@@ -828,9 +1040,9 @@ static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_
         rng_uniform4(g, tmp);                                       /* :27 */
         f2 sample_scatter = { tmp[0], tmp[1] };
         rec_init(&rec);                                             /* :29 */
-        if (bounces > max_depth) {
-            /* :31 traces this ray too, but with Lambertian surfaces and no
-             * environment light nothing reads the result before the break at :64. */
+        if (bounces > max_depth && !(specular_bounce && s->n_tri_lights > 0)) {
+            /* :31 traces this ray too, but nothing reads the result before the break at :64
+             * unless the ray left a specular surface and there is a light to land on (:33-52). */
             break;
         }
         ishit = scene_hit(s, &r, &rec);                             /* :31 */
@@ -842,17 +1054,17 @@ static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_
             cnt->bounce++;
         }
         rec.wo = r;                                                 /* :32 */
-        /* :33-52 emission of a triangle light the camera ray (or, with specular materials --
-         * none in scope -- a specular bounce) lands on; :53-61 environment light: out of scope */
-        if (bounces == 0 && ishit && rec.isLight && rec.light_type >= ORC_LIGHT_TRIANGLE &&
-            rec.lightidx >= 0 && rec.lightidx < s->n_tri_lights) {
+        /* :33-52 emission of a triangle light the camera ray, or a ray off a specular surface,
+         * lands on; :53-61 environment light: out of scope */
+        if ((bounces == 0 || specular_bounce) && ishit && rec.isLight &&
+            rec.light_type >= ORC_LIGHT_TRIANGLE && rec.lightidx >= 0 && rec.lightidx < s->n_tri_lights) {
             tl_t l = tl_load(s, rec.lightidx);
             res = add3(res, mul3(beta, tl_L(&l, neg3(r.d))));       /* :47 */
         }
         if (!ishit || bounces > max_depth)                          /* :64 */
             break;
-        int specular = rec.material_type & ORC_MAT_SPECULAR_BIT;    /* :67 */
-        if (!specular) {
+        specular_bounce = rec.material_type & ORC_MAT_SPECULAR_BIT; /* :67 */
+        if (!specular_bounce) {
             le = sample_all_light(s, &rec, g, cnt);                 /* :72 */
             res = add3(res, mul3(beta, le));                        /* :73 */
         }

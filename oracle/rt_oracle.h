@@ -67,6 +67,8 @@ typedef struct orc_scene {
     const int32_t *tl_two_side; /* [n_tri_lights]     two */
     const int32_t *tl_mat_type; /* [n_tri_lights]     material_type[n_models + k] (Scene.cu:151-153) */
     const float *tl_color;    /* [n_tri_lights][3]    Lambertian::color of Material[n_models + k] */
+    const float *model_param; /* [n_models][2] (roughness, eta): the second constructor argument of GGX /
+                                 Cook_Torrance (material.cuh:48,88) and of Fresnel (:112); NULL = zeros */
 } orc_scene;
 
 /* The 7 constructor arguments of Camera (reference Camera/Camera.cuh:11). */
@@ -121,6 +123,9 @@ int orc_trace_ray(const orc_scene *scene, const float org[3], const float dir[3]
 /* Philox4x32-10 block and the cuRAND-style float mapping (H7). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void orc_pixel_uniform4(uint32_t pixel_index, uint32_t draw, float out[4]);
+
+/* rough2alpha (material.cuh:7-13). */
+float orc_rough2alpha(float rough);
 
 /* The deterministic sinf/cosf the build fixes for sampleHemi (material.cu:46). */
 float orc_sinf(float x);

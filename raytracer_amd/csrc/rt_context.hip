@@ -478,7 +478,9 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     TriRec *tris = nullptr; TriCold *cold = nullptr; ModelRec *models = nullptr;
     SphereRec *spheres = nullptr; LightRec *lights = nullptr;
     NodeGroup *nodes = nullptr; uint32_t *pos_of = nullptr; TriLightRec *tlights = nullptr;
+    MatRec *mats = nullptr;
     if ((rc = dalloc(c, c->scene_allocs, tlights, hs.tlights.size()))) return rc;
+    if ((rc = dalloc(c, c->scene_allocs, mats, hs.mats.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, tris, hs.tris.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, cold, hs.cold.size()))) return rc;
     if ((rc = dalloc(c, c->scene_allocs, pos_of, hs.pos_of.size()))) return rc;
@@ -497,8 +499,11 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     RT_HIP(c, up(spheres, hs.spheres.data(), hs.spheres.size() * sizeof(SphereRec)));
     RT_HIP(c, up(lights, hs.lights.data(), hs.lights.size() * sizeof(LightRec)));
     RT_HIP(c, up(tlights, hs.tlights.data(), hs.tlights.size() * sizeof(TriLightRec)));
+    RT_HIP(c, up(mats, hs.mats.data(), hs.mats.size() * sizeof(MatRec)));
     v.tlights = tlights;
     v.n_tlights = (int)hs.tlights.size();
+    v.mats = mats;
+    v.general = hs.general ? 1 : 0;
     v.tris = tris; v.tri_pos_of = pos_of; v.tri_cold = cold; v.models = models;
     v.spheres = spheres; v.lights = lights;
     v.n_tris = (int)hs.cold.size();
@@ -570,7 +575,7 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
     hipStream_t s0 = c->stream;
-    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3 && c->v.n_tlights == 0) {
+    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3 && !c->v.general) {
         // Depth 0 over a deep tree, one kernel per batch of samples and lane (k_batch,
         // rt_kernels.hip): camera rays from predicted counters, shadow rays and the running mean
         // of a unit without leaving the wave.  The lanes' launches follow each other on their own

@@ -530,6 +530,200 @@ __device__ __forceinline__ v3 rec_sample_f_y(const Hit &h, const ModelRec &M, fl
     return res;
 }
 
+// ------------------------------------------------------------------ every BRDF (general kernel)
+// acosf / sinf / cosf / logf / powf of material.cu:84-254 are not bit-specified; the build fixes
+// each as the float rounding of the double-precision function, here and in the oracle alike.
+__device__ __forceinline__ float m_acosf(float x) { return (float)acos((double)x); }
+__device__ __forceinline__ float m_sinf(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float m_cosf(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float m_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+
+__device__ __forceinline__ v3 world2local(const Hit &h, v3 w)                     // Object.cu:107-110
+{
+    return mk3(dot(w, h.tangent), dot(w, h.normal), dot(w, normalize(cross(h.tangent, h.normal))));
+}
+// GGX::SchlickFresnel (material.cu:85-90) = Cook_Torrance::F (material.cuh:96-101)
+__device__ __forceinline__ v3 schlick(v3 r0, float r)
+{
+    float t = (1.0f - r);
+    v3 a = mk3(1.0f - r0.x, 1.0f - r0.y, 1.0f - r0.z);
+    a = scale(scale(scale(a, t * t), t * t), t);
+    return add(r0, a);
+}
+// GGX::G (material.cu:92-98) = Cook_Torrance::G (:192-198)
+__device__ __forceinline__ float smith_g(float a2, v3 wi, v3 wo)
+{
+    float A = wo.y * sqrtf(a2 + (1.0f - a2) * wi.y * wi.y);
+    float B = wi.y * sqrtf(a2 + (1.0f - a2) * wo.y * wo.y);
+    return 2.0f * wo.y * wi.y / (A + B);
+}
+// GGX::D (material.cu:100-103; M_PI makes the expression double)
+__device__ __forceinline__ float ggx_d(float a2, v3 wh)
+{
+    float k = wh.y * wh.y * (a2 - 1) + 1;
+    return (float)((double)a2 / (3.14159265358979323846 * (double)k * (double)k));
+}
+__device__ __forceinline__ v3 ggx_f(float a2, v3 wo, v3 wi, v3 c)                // material.cu:105-114
+{
+    float dotwin_won = fmaxf(0.0001f, fabsf(4.0f * wi.y * wo.y));
+    v3 wh = normalize(add(wo, wi));
+    return divs(scale(scale(schlick(c, dot(wi, wh)), ggx_d(a2, wh)), smith_g(a2, wi, wo)), dotwin_won);
+}
+__device__ __forceinline__ float ggx_pdf(float a2, v3 wo, v3 wi)                 // material.cu:132-137
+{
+    v3 wh = normalize(add(wo, wi));
+    return wi.y > 0.0f && dot(wi, wh) > 0.0f ? ggx_d(a2, wh) * wh.y * 0.25f / wo.y : 0.0f;
+}
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return v < lo ? lo : hi < v ? hi : v; }
+// Oren_Nayar::f (material.cu:140-170), sigma = 0.5; A, B, TanBeta are double expressions
+// narrowed to float; SinPhiO divides by SinThetaI as written (:154)
+__device__ __forceinline__ v3 oren_f(v3 wo, v3 wi, v3 c)
+{
+    float sigma = 0.5;
+    float A = (float)(1 - 0.5 * sigma * sigma / (sigma * sigma + 0.33));
+    float B = (float)(0.45 * sigma * sigma / (sigma * sigma + 0.09));
+    float CosThetaI = wi.y, CosThetaO = wo.y;
+    float SinThetaI = sqrtf(1 - CosThetaI * CosThetaI);
+    float SinThetaO = sqrtf(1 - CosThetaO * CosThetaO);
+    float CosPhiI = (SinThetaI == 0) ? 1 : clampf(wi.x / SinThetaI, -1, 1);
+    float CosPhiO = (SinThetaO == 0) ? 0 : clampf(wo.x / SinThetaO, -1, 1);
+    float SinPhiI = (SinThetaI == 0) ? 1 : clampf(wi.z / SinThetaI, -1, 1);
+    float SinPhiO = (SinThetaO == 0) ? 0 : clampf(wo.z / SinThetaI, -1, 1);
+    float dCos = CosPhiI * CosPhiO + SinPhiI * SinPhiO;
+    float maxCos = (dCos > 0) ? dCos : 0;
+    float SinAlpha, TanBeta;
+    if (CosThetaI * CosThetaI > CosThetaO * CosThetaO) {
+        SinAlpha = SinThetaO;
+        TanBeta = (float)(SinThetaI * 1.0 / ((CosThetaI > 0) ? CosThetaI : (-1 * CosThetaI)));
+    } else {
+        SinAlpha = SinThetaI;
+        TanBeta = (float)(SinThetaI * 1.0 / ((CosThetaO > 0) ? CosThetaO : (-1 * CosThetaO)));
+    }
+    return (wo.y > 0.0f && wi.y > 0.0f) ? scale(scale(c, kInvPi), A + B * maxCos * SinAlpha * TanBeta)
+                                        : mk3(0.0f, 0.0f, 0.0f);
+}
+// Cook_Torrance::D (material.cu:241-245): pow(float, int) is double, pow(float, float) powf
+__device__ __forceinline__ float cook_d(float m, v3 wo)
+{
+    float c = (float)(1.0 / ((double)(m * m) * pow((double)wo.y, 4.0)));
+    return c * m_powf(2.718281828f, -(m_acosf(wo.y) * m_acosf(wo.y)) / (m * m));
+}
+__device__ __forceinline__ v3 cook_f(const MatRec &P, v3 wo, v3 wi, v3 c)        // material.cu:200-208
+{
+    float dotwin_won = fmaxf(0.0001f, fabsf(4.0f * wi.y * wo.y));
+    v3 wh = normalize(add(wo, wi));
+    return divs(scale(scale(schlick(c, dot(wi, wh)), cook_d(P.m, wh)), smith_g(P.a2, wi, wo)), dotwin_won);
+}
+__device__ __forceinline__ float cook_pdf(const MatRec &P, v3 wo, v3 wi)         // material.cu:246-254
+{
+    if (!(wo.y * wi.y > 0))
+        return 0;
+    v3 wh = normalize(add(wo, wi));
+    if (dot(wo, wh) == 0.0f)
+        return 0.0f;
+    return cook_d(P.m, wh) / (4 * dot(wo, wh));
+}
+// Fresnel::sample_f (material.cuh:118-152)
+__device__ __forceinline__ v3 fresnel_sample_f(float eta, v3 wo, v3 &wi, float &pdf, float sx, v3 c)
+{
+    bool entering = wo.y > 0.0f;
+    float n1 = 1.0f, n2 = eta;
+    float R = (n1 - n2) / (n1 + n2);
+    R *= R;
+    float t = fabsf(wo.y);
+    float F = R + (t * t) * (t * t) * t * (1.0f - R);
+    if (sx < F) {
+        pdf = F;
+        wi = mk3(-wo.x, wo.y, -wo.z);
+        return divs(scale(c, F), fmaxf(fabsf(wi.y), 0.0000001f));
+    }
+    pdf = 1 - F;
+    float etas;
+    float sin2theta = fmaxf(0.001f, 1.0f - wo.y * wo.y);
+    if (!entering)
+        etas = 1.0f / eta;
+    else
+        etas = eta;
+    if (sin2theta * etas * etas >= 1.0f)
+        return mk3(0.0f, 0.0f, 0.0f);
+    float costhetaT = sqrtf(1.0f - etas * etas * sin2theta);
+    wi = add(scale(wo, -etas), scale(mk3(0.0f, 1.0f, 0.0f), etas * wo.y - costhetaT));
+    wi = normalize(wi);
+    return divs(scale(c, 1.0f - F), fmaxf(fabsf(wi.y), 0.0000001f));
+}
+
+__device__ __forceinline__ v3 brdf_color(const Hit &h, const ModelRec &M)
+{
+    return h.color.x < 0.0f ? mk3(M.color[0], M.color[1], M.color[2]) : h.color;   // `if (c.x < 0.0f) c = color`
+}
+// Material::f (Object.cu:3-32), world-space directions
+__device__ __forceinline__ v3 brdf_f(const Hit &h, const ModelRec &M, const MatRec &P, v3 wo, v3 wi)
+{
+    const v3 lo = world2local(h, wo), li = world2local(h, wi), c = brdf_color(h, M);
+    switch (M.mat_type) {
+    case kMatLambertian: return (lo.y > 0.0f && li.y > 0.0f) ? scale(c, kInvPi) : mk3(0.0f, 0.0f, 0.0f);
+    case kMatGGX: return ggx_f(P.a2, lo, li, c);
+    case kMatCook: return cook_f(P, lo, li, c);
+    case kMatOrenNayar: return oren_f(lo, li, c);
+    default: return mk3(0.0f, 0.0f, 0.0f);                                       // FRESNEL: BLACK
+    }
+}
+// Material::PDF (Object.cu:74-104)
+__device__ __forceinline__ float brdf_pdf(const Hit &h, const ModelRec &M, const MatRec &P, v3 wo, v3 wi)
+{
+    const v3 lo = world2local(h, wo), li = world2local(h, wi);
+    switch (M.mat_type) {
+    case kMatLambertian:
+    case kMatOrenNayar: return li.y > +0.0f ? li.y * kInvPi : 0.0f;
+    case kMatGGX: return ggx_pdf(P.a2, lo, li);
+    case kMatCook: return cook_pdf(P, lo, li);
+    default: return 0.0f;
+    }
+}
+// Material::sample_f (Object.cu:34-72).  wi is in/out: Cook_Torrance::sample_f overwrites its
+// sampled half vector with normalize(wo + *wi), *wi being the caller's variable as it comes in
+// (material.cu:229, hazard H9).
+__device__ __forceinline__ v3 brdf_sample_f(const Hit &h, const ModelRec &M, const MatRec &P, v3 wo, v3 &wi,
+                                            float &pdf, float sx, float sy)
+{
+    const v3 lo = world2local(h, wo), c = brdf_color(h, M);
+    v3 res = mk3(0.0f, 0.0f, 0.0f);
+    switch (M.mat_type) {
+    case kMatLambertian:
+        wi = sample_hemi(sx, sy);
+        pdf = wi.y > +0.0f ? wi.y * kInvPi : 0.0f;
+        res = (lo.y > 0.0f && wi.y > 0.0f) ? scale(c, kInvPi) : mk3(0.0f, 0.0f, 0.0f);
+        break;
+    case kMatOrenNayar:                                                          // material.cu:171-188
+        wi = sample_hemi(sx, sy);
+        pdf = wi.y > +0.0f ? wi.y * kInvPi : 0.0f;
+        res = oren_f(lo, wi, c);
+        break;
+    case kMatFresnel:
+        res = fresnel_sample_f(P.eta, lo, wi, pdf, sx, c);
+        break;
+    case kMatGGX: {                                                              // material.cu:116-130
+        float theta = m_acosf(sqrtf((1.0f - sx) / ((P.a2 - 1.0f) * sx + 1.0f)));
+        float phi = (float)((double)sy * 3.14159265358979323846 * (double)2.0f);
+        v3 wh = mk3(m_sinf(theta) * m_sinf(phi), m_cosf(theta), m_cosf(phi) * m_sinf(theta));
+        wi = sub(scale(wh, 2.0f * dot(lo, wh)), lo);
+        pdf = ggx_pdf(P.a2, lo, wi);
+        res = ggx_f(P.a2, lo, wi, c);
+        break;
+    }
+    case kMatCook: {                                                             // material.cu:209-234
+        v3 wh = normalize(add(lo, wi));                                          // :229
+        wi = sub(scale(wh, 2.0f * dot(lo, wh)), lo);                             // :230
+        pdf = cook_pdf(P, lo, wi);
+        res = cook_f(P, lo, wi, c);
+        break;
+    }
+    default: break;
+    }
+    wi = local2world(h, wi);
+    return res;
+}
+
 // black(x) = length(x) < 0.001f (Scene.cu:3-5) and the `length(f) < 0.0001f` of PathTracer.cu:77, without the
 // square root: sqrtf is correctly rounded and monotone, so sqrtf(y) < c holds exactly for the y below
 // the smallest float whose root reaches c -- 0x1.0c6f7ap-20 for c = 0.001f, 0x1.5798ecp-27 for

@@ -97,6 +97,8 @@ struct DevView {
     int cull;                       // 0: scan every triangle (validation), 1: use the tree
     int sorted_planes;              // 1: waves whose rays share an octant read the boxes' planes pre-ordered
     const ModelRec *models;
+    const MatRec *mats;             // per ModelRec: the BRDF's parameters (general kernel only)
+    int general;                    // 1: non-Lambertian materials or triangle lights -> k_path_general
     const SphereRec *spheres;
     const LightRec *lights;         // delta lights (point, then directional)
     const TriLightRec *tlights;     // triangle lights: hit-able (Scene.cu:43-64), sampled with MIS (Scene.cu:242-284)

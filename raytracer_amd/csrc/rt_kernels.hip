@@ -883,31 +883,39 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
     }
 }
 
-// ------------------------------------------------------------------ scenes with triangle lights
-// The same chunk of 128 pixels, for scenes that hold TriangleLights.  What changes
+// ------------------------------------------------------------------ the general path
+// The same chunk of 128 pixels for scenes beyond the bench configurations' Lambertian models under
+// delta lights: TriangleLights and every BRDF of material.cu.  What changes
 // against path_chunk:
-//   * every ray's closest hit also tests the lights, after the models (traverse<.., LIGHTS>);
-//   * the camera ray's hit on a light adds its emission (PathTracer.cu:33-52);
-//   * a light's surface is shaded like any other (its own Lambertian Material, the unnormalised
-//     normal of Light.cu:72,97);
+//   * every ray's closest hit also tests the triangle lights, after the models (traverse<.., LIGHTS>);
+//   * a hit on a light adds its emission for camera rays and rays off specular surfaces
+//     (PathTracer.cu:33-52); a light's surface is shaded like any other (its own Lambertian
+//     Material, the unnormalised normal of Light.cu:72,97);
 //   * Scene::sampleAllLight (Scene.cu:69-124) goes on after the delta lights with one MIS
 //     estimate per triangle light (Scene.cu:205-287, isDelta = false): a shadow ray towards a
 //     point sampled on the light (phase A) and a ray along the BRDF's own sample (phase B), both
 //     closest-hit queries whose verdict needs `lightidx == idx`;
+//   * Material::f / sample_f / PDF dispatch over Lambertian, GGX, Cook_Torrance, Oren_Nayar and
+//     Fresnel (Object.cu:3-104); specular surfaces skip sampleAllLight (PathTracer.cu:67-74), and
+//     the ray that leaves one at the depth limit is still traced when there is a light it can land
+//     on (PathTracer.cu:31-52 run before the break of :64);
 //   * no occlusion shortcut and no LDS stash: this is the feature path, kept plain.  The bench
-//     configurations (delta lights only) never come here.
-struct AreaState {
+//     configurations never come here.
+struct GeneralState {
     uint32_t draw0;                  // Philox draw of this bounce's tmp (PathTracer.cu:27); light q draws draw0 + 1 + q
-    float wo_y;
+    v3 wo;                           // -r.dir of the ray that found the hit
     Hit H;
     v3 le, cur, contrib;             // sampleAllLight's res; the current light's res; the term under test
     float thr;
     bool go_on;                      // the current area light passed `pdf_light >= 0.001` (Scene.cu:233)
+    bool from_specular;              // the ray being traced left a specular surface (specular_bounce)
+    bool last;                       // ... at the depth limit: only its emission is still read
+    v3 wi;                           // PathTracer.cu:18 `wi`: what Cook_Torrance::sample_f reads on entry (H9)
     v3 beta, res;
 };
 
 template <bool CULL>
-__device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane)
+__device__ __forceinline__ void path_chunk_general(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane)
 {
     const DevView &v = A.v;
     const int Ld = v.n_lights, La = v.n_tlights, L = Ld + La;
@@ -916,8 +924,8 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
     uint32_t cost = 0, n_shadow = 0, n_bounce = 0;
     Stamps sp0;
     auto pixel_of = [&](int h) { return A.p0 + min(chunk * kPathChunk + (uint32_t)h * 64u + lane, A.n - 1u); };
-    bool mine[2], alive[2], ishit[2] = {false, false}, cast[2] = {false, false};
-    AreaState S[2];
+    bool mine[2], alive[2], lit[2] = {false, false}, ishit[2] = {false, false}, cast[2] = {false, false};
+    GeneralState S[2];
     uint32_t draw[2];
     const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
     RayPair w;
@@ -932,7 +940,7 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
         return r;
     };
     // rec.pos of the closest hit of the ray just traced (Scene.cu:227 reads it)
-    auto hit_pos = [&](int h, const Ray &sr, float best, int32_t sid) {
+    auto hit_pos = [&](const Ray &sr, float best, int32_t sid) {
         return (sid >= v.n_tris && sid < n_models_prims) ? hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best)
                                                          : ray_pos(sr, best);
     };
@@ -949,9 +957,10 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
         int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
         Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
         ro[h] = r.o; rd[h] = r.d;
-        S[h] = AreaState{};
+        S[h] = GeneralState{};
         S[h].beta = mk3(1.0f, 1.0f, 1.0f);
         S[h].res = mk3(0.0f, 0.0f, 0.0f);
+        S[h].wi = mk3(0.0f, 0.0f, 0.0f);                     // H9
     }
     for (int bounce = 0;; bounce++) {
         // ---- closest hit of this bounce: PathTracer.cu:27-64
@@ -961,6 +970,7 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
             const float t = h ? w.best.y : w.best.x;
             const int32_t id = h ? w.idy : w.idx;
             ishit[h] = alive[h] && scene_ishit(t) && id >= 0;
+            lit[h] = false;
             S[h].le = mk3(0.0f, 0.0f, 0.0f);
             if (!alive[h])
                 continue;
@@ -969,40 +979,63 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                 v.first_id[p] = id;
                 v.first_t[p] = t;
             }
+            const Ray r = ray_of(h);
+            const bool on_light = ishit[h] && id >= n_models_prims;
+            if (on_light && (bounce == 0 || S[h].from_specular))             // PathTracer.cu:33-47
+                S[h].res = add(S[h].res, mul(S[h].beta, light_L(v.tlights[id - n_models_prims], neg(r.d))));
+            if (S[h].last) {                                 // traced for its emission only: the break of :64
+                ishit[h] = false;
+                finalize_path(v, p, S[h].res);
+                alive[h] = false;
+                continue;
+            }
             S[h].draw0 = draw[h];
-            draw[h] += 1u + (ishit[h] ? (uint32_t)L : 0u);   // tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
+            draw[h] += 1u;                                   // tmp (PathTracer.cu:27)
             if (!ishit[h]) {                                 // PathTracer.cu:64
                 finalize_path(v, p, S[h].res);
                 alive[h] = false;
                 continue;
             }
-            const Ray r = ray_of(h);
-            if (id >= n_models_prims) {
-                const TriLightRec &Lr = v.tlights[id - n_models_prims];
-                fill_light_hit(Lr, r, t, S[h].H);
-                if (bounce == 0)                             // PathTracer.cu:33-47 (no specular materials in scope)
-                    S[h].res = add(S[h].res, mul(S[h].beta, light_L(Lr, neg(r.d))));
-            } else {
+            if (on_light)
+                fill_light_hit(v.tlights[id - n_models_prims], r, t, S[h].H);
+            else
                 fill_hit(v, r, id, S[h].H);
-            }
-            S[h].wo_y = local_y(S[h].H, neg(r.d));
+            S[h].wo = neg(r.d);
+            lit[h] = !(v.models[S[h].H.model].mat_type & kMatSpecularBit);   // PathTracer.cu:67-70
+            if (lit[h])
+                draw[h] += (uint32_t)L;                      // one draw per light (Scene.cu:87)
         }
-        if (__ballot(ishit[0] | ishit[1])) {
+        if (__ballot(lit[0] | lit[1])) {
             // ---- Scene::sampleAllLight: delta lights (Scene.cu:93-102)
             for (int j = 0; j < Ld; j++) {
                 const LightRec light = load_uniform(&v.lights[j]);
+                const v3 lp = mk3(light.pos[0], light.pos[1], light.pos[2]),
+                         illum = mk3(light.illum[0], light.illum[1], light.illum[2]);
                 v3 so[2], sd[2];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     cast[h] = false;
                     so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
-                    if (ishit[h]) {
-                        LightSample s = sample_point_light(S[h].H, v.models[S[h].H.model], S[h].wo_y, light);
-                        cast[h] = s.cast;
-                        so[h] = s.sr.o; sd[h] = s.sr.d;
-                        S[h].thr = s.thr;
-                        S[h].contrib = s.contrib;
+                    if (!lit[h])
+                        continue;
+                    const Hit &H = S[h].H;
+                    Ray wi;
+                    v3 color;
+                    if (light.type == kLightPoint) {
+                        wi = make_ray(lp, sub(H.pos, lp));                            // Light.cu:9
+                        v3 dd = sub(H.pos, lp);
+                        color = divs(illum, fmaxf(0.001f, dot(dd, dd)));              // Light.cu:13
+                    } else {
+                        wi = make_ray(sub(H.pos, scale(lp, 10000.0f)), lp);           // Light.cu:25
+                        color = illum;                                                // Light.cu:27
                     }
+                    const Ray sr = spawn_ray(H, neg(wi.d));                           // Scene.cu:218
+                    const v3 f = scale(brdf_f(H, v.models[H.model], v.mats[H.model], S[h].wo, sr.d),
+                                       fabsf(dot(H.normal, sr.d)));                   // Scene.cu:222
+                    cast[h] = !is_black(f);                                           // Scene.cu:224
+                    so[h] = sr.o; sd[h] = sr.d;
+                    S[h].thr = length(sub(sr.o, wi.o)) - 0.01f;                       // Scene.cu:227 rhs
+                    S[h].contrib = is_black(color) ? mk3(0.0f, 0.0f, 0.0f) : divs(mul(color, f), 1.0f);   // :236-240
                 }
                 const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
                 if (!(c0 | c1))
@@ -1018,7 +1051,7 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                     bool blocked = false;                    // H3: `lightidx == idx` never true for delta lights
                     if (scene_ishit(best) && sid >= 0) {
                         const Ray sr = ray_of(h);
-                        blocked = length(sub(hit_pos(h, sr, best, sid), sr.o)) < S[h].thr;   // Scene.cu:227
+                        blocked = length(sub(hit_pos(sr, best, sid), sr.o)) < S[h].thr;   // Scene.cu:227
                     }
                     if (!blocked)
                         S[h].le = add(S[h].le, S[h].contrib);
@@ -1038,12 +1071,13 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                     S[h].cur = mk3(0.0f, 0.0f, 0.0f);
                     S[h].contrib = mk3(0.0f, 0.0f, 0.0f);
                     S[h].go_on = false;
-                    if (!ishit[h])
+                    if (!lit[h])
                         continue;
                     float u[4];
                     pixel_uniform4(v.pixmap[pixel_of(h)], S[h].draw0 + 1u + (uint32_t)(Ld + k), u);   // Scene.cu:87-89
                     const Hit &H = S[h].H;
                     const ModelRec &M = v.models[H.model];
+                    const MatRec &P = v.mats[H.model];
                     const float sq_x = sqrtf(u[0]);                                   // Light.cu:49
                     v3 ts = mk3(1 - sq_x, u[1] * sq_x, 0.0f);
                     ts.z = 1.0f - ts.x - ts.y;
@@ -1052,14 +1086,13 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                     const float pdf_light = light_pdf(Lr, length(sub(H.pos, lp)), wi.d);   // Light.cu:58-61
                     const v3 color = light_L(Lr, wi.d);                               // Light.cu:64
                     const Ray sr = spawn_ray(H, neg(wi.d));                           // Scene.cu:218
-                    const v3 f = scale(rec_f_y(H, M, S[h].wo_y, sr.d), fabsf(dot(H.normal, sr.d)));   // :222
+                    const v3 f = scale(brdf_f(H, M, P, S[h].wo, sr.d), fabsf(dot(H.normal, sr.d)));   // :222
                     cast[h] = !is_black(f);                                           // :224
                     so[h] = sr.o; sd[h] = sr.d;
                     S[h].thr = length(sub(sr.o, lp)) - 0.01f;                         // :227 rhs
                     S[h].go_on = !(pdf_light < 0.001f);                               // :233
                     if (S[h].go_on && cast[h] && !is_black(color)) {                  // :236
-                        const float wy = local_y(H, sr.d);
-                        const float pdf_surface = wy > +0.0f ? wy * kInvPi : 0.0f;    // :244, material.cu:79-82
+                        const float pdf_surface = brdf_pdf(H, M, P, S[h].wo, sr.d);   // :244
                         float weight = pdf_light * pdf_light / (pdf_light * pdf_light + pdf_surface * pdf_surface);   // :245
                         weight /= pdf_light;                                          // :246
                         S[h].contrib = scale(mul(color, f), weight);                  // :247
@@ -1079,7 +1112,7 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                             bool blocked = false;
                             if (scene_ishit(best) && sid >= 0 && sid != n_models_prims + k) {   // :227 lightidx == idx
                                 const Ray sr = ray_of(h);
-                                blocked = length(sub(hit_pos(h, sr, best, sid), sr.o)) < S[h].thr;
+                                blocked = length(sub(hit_pos(sr, best, sid), sr.o)) < S[h].thr;
                             }
                             if (!blocked)
                                 S[h].cur = S[h].contrib;                              // :249 (BLACK when :236 failed)
@@ -1091,15 +1124,14 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                 for (int h = 0; h < 2; h++) {
                     cast[h] = false;
                     so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
-                    if (!ishit[h] || !S[h].go_on)
+                    if (!lit[h] || !S[h].go_on)
                         continue;
                     float u[4];
                     pixel_uniform4(v.pixmap[pixel_of(h)], S[h].draw0 + 1u + (uint32_t)(Ld + k), u);
                     const Hit &H = S[h].H;
-                    const ModelRec &M = v.models[H.model];
-                    v3 wi;
-                    float pdf_surface;
-                    v3 f = rec_sample_f_y(H, M, S[h].wo_y, wi, pdf_surface, u[2], u[3]);   // :258
+                    v3 wi = mk3(0.0f, 0.0f, 0.0f);                                    // :253 uninitialised: H9
+                    float pdf_surface = 0.0f;
+                    v3 f = brdf_sample_f(H, v.models[H.model], v.mats[H.model], S[h].wo, wi, pdf_surface, u[2], u[3]);   // :258
                     f = scale(f, fabsf(dot(H.normal, wi)));                           // :259
                     const Ray r = spawn_ray(H, wi);                                   // :260
                     if (is_black(f) || !(pdf_surface > 0.001f))                       // :264
@@ -1130,7 +1162,7 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                 }
 #pragma unroll
                 for (int h = 0; h < 2; h++)
-                    if (ishit[h])
+                    if (lit[h])
                         S[h].le = add(S[h].le, S[h].cur);                             // Scene.cu:120
             }
         }
@@ -1142,14 +1174,14 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
             if (!ishit[h])
                 continue;
             const uint32_t p = pixel_of(h);
-            S[h].res = add(S[h].res, mul(S[h].beta, S[h].le));           // PathTracer.cu:73
+            if (lit[h])
+                S[h].res = add(S[h].res, mul(S[h].beta, S[h].le));       // PathTracer.cu:73
             const Hit &H = S[h].H;
-            const ModelRec &M = v.models[H.model];
             float u[4];
             pixel_uniform4(v.pixmap[p], S[h].draw0, u);                  // tmp of PathTracer.cu:27
-            v3 wi;
-            float pdf;
-            v3 f = rec_sample_f_y(H, M, S[h].wo_y, wi, pdf, u[0], u[1]);   // PathTracer.cu:76
+            float pdf = 0.0f;
+            v3 f = brdf_sample_f(H, v.models[H.model], v.mats[H.model], S[h].wo, S[h].wi, pdf, u[0], u[1]);   // :76
+            const v3 wi = S[h].wi;
             bool done = (pdf < 0.0001f || len_below_1e4(f));             // PathTracer.cu:77
             if (!done) {
                 S[h].beta = mul(S[h].beta, divs(scale(f, fabsf(dot(wi, H.normal))), pdf));   // :79
@@ -1162,17 +1194,23 @@ __device__ __forceinline__ void path_chunk_area(const PathArgs &A, const ChunkEn
                         S[h].beta = divs(S[h].beta, 1.0f - 0.5f);
                 }
             }
+            S[h].from_specular = !lit[h];                                // :67
             if (!done && bounce + 1 > A.max_depth) {
-                // next iteration: one draw (:27), a trace whose result nothing reads (bounces >= 1:
-                // no emission, :33), then the break of :64
+                // next iteration: one draw (:27) and a trace (:31) that only the emission test of
+                // :33-52 can read -- off a specular surface, with a light to land on -- then the
+                // break of :64
                 draw[h] += 1u;
-                done = true;
+                if (S[h].from_specular && La > 0)
+                    S[h].last = true;
+                else
+                    done = true;
             }
             if (done) {
                 finalize_path(v, p, S[h].res);
                 alive[h] = false;
             }
             ishit[h] = false;
+            lit[h] = false;
         }
         const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]);
         if (!(a0 | a1))
@@ -1302,7 +1340,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
 }
 
 template <bool CULL>
-__global__ __launch_bounds__(kBlock, 2) void k_path_area(const PathArgs A, uint32_t *__restrict__ work,
+__global__ __launch_bounds__(kBlock, 1) void k_path_general(const PathArgs A, uint32_t *__restrict__ work,
                                                          uint32_t *__restrict__ work_next, int dynamic)
 {
     __shared__ uint32_t s_chunk;
@@ -1312,8 +1350,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_path_area(const PathArgs A, uint3
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     run_chunks<CULL>(
         n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t chunk) { path_chunk_area<CULL>(A, env, chunk, lane); },
-        [&](uint32_t chunk) { path_chunk_area<CULL>(A, env, chunk, lane); });   // (never: no feedback here)
+        [&](uint32_t chunk) { path_chunk_general<CULL>(A, env, chunk, lane); },
+        [&](uint32_t chunk) { path_chunk_general<CULL>(A, env, chunk, lane); });   // (never: no feedback here)
 }
 
 // ------------------------------------------------------------------ depth 0: whole batches of samples
@@ -2199,13 +2237,13 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // cooperative form shortens (measured on 1/8 partitions of C3 and C4: 2x and 4x best).
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves * (kBlock / 64);
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
-    if (v.n_tlights > 0) {
-        // scenes with triangle lights: the plain general kernel, without chunk feedback
+    if (v.general) {
+        // triangle lights or non-Lambertian materials: the plain general kernel, without chunk feedback
         A.fb = ChunkFeedback{};
         A.occlusion = false;
         const uint32_t ga = grid_for_chunks(n, max_blocks * 2);
-        if (v.cull) k_path_area<true><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else        k_path_area<false><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        if (v.cull) k_path_general<true><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else        k_path_general<false><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
         return;
     }
     if (v.cull) {

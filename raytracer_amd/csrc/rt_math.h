@@ -144,6 +144,7 @@ constexpr float kPiOver4 = 0.78539816339744830961f;  // material.cu:7
 constexpr float kPiOver2 = 1.57079632679489661923f;  // material.cu:8
 constexpr int kMatLambertian = 1;           // Material/Object.cuh:15
 constexpr int kMatSpecularBit = 4;          // Material/Object.cuh:10
+constexpr int kMatFresnel = 7, kMatCook = 9, kMatGGX = 17, kMatOrenNayar = 25;   // Object.cuh:16-19
 
 // ---- device-resident scene records (built on the host at upload) ----
 // One 64-byte record per triangle.  Every arithmetic field is a ray-independent
@@ -197,6 +198,15 @@ struct ModelRec {
     m4 cas;             // transpose(inverse(transformation)), Model.cu:126
     float color[3];     // Lambertian::color
     int32_t mat_type;   // material::MATERIAL_TYPE
+};
+
+// The BRDF object behind a model's Material as its constructor leaves it (material.cuh:48,88,112);
+// read only by the general kernel (non-Lambertian materials, triangle lights).
+struct MatRec {
+    float a2;           // GGX: rough2alpha(roughness)^2; Cook_Torrance: m * m
+    float m;            // Cook_Torrance: rough2alpha(rough)
+    float eta;          // Fresnel
+    float pad;
 };
 
 struct SphereRec {

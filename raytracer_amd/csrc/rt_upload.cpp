@@ -403,12 +403,19 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
             err = "a triangle light's own material must be LAMBERTIAN (Light.cu:115-125)";
             return RT_ERR_UNSUPPORTED;
         }
-    for (int m = 0; m < n_models; m++)
-        if (d->model_mat_type[m] != kMatLambertian) {
-            err = "only LAMBERTIAN materials are on the hot path (GGX/Cook/Oren-Nayar/Fresnel: "
-                  "SURVEY section 8(f) N4)";
+    out.general = d->n_tri_lights > 0;
+    for (int m = 0; m < n_models; m++) {
+        const int t = d->model_mat_type[m];
+        if (t != kMatLambertian && t != kMatFresnel && t != kMatCook && t != kMatGGX && t != kMatOrenNayar) {
+            err = "unknown material::MATERIAL_TYPE (Object.cuh:13-21: 1, 7, 9, 17, 25)";
             return RT_ERR_UNSUPPORTED;
         }
+        if ((t == kMatFresnel || t == kMatCook || t == kMatGGX) && !d->model_param) {
+            err = "model_param is NULL but a GGX / Cook_Torrance / Fresnel material needs its roughness / eta";
+            return RT_ERR_INVALID;
+        }
+        if (t != kMatLambertian) out.general = true;
+    }
 
     out.tris.resize((size_t)d->n_tris);
     out.cold.resize((size_t)d->n_tris);
@@ -423,6 +430,19 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
         out.models[m].mat_type = d->model_mat_type[m];
     }
 
+    // the BRDF objects as their constructors leave them (material.cuh:7-13,48,88,112); logf as
+    // the oracle fixes it: the float rounding of the double-precision log
+    out.mats.assign((size_t)n_models + (size_t)d->n_tri_lights, MatRec{});
+    for (int m = 0; m < n_models; m++) {
+        float rough = d->model_param ? d->model_param[2 * (size_t)m] : 0.0f;
+        rough = std::fmax(rough, 1e-3f);
+        const float x = (float)std::log((double)rough);
+        const float alpha = 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x +
+                            0.000640711f * x * x * x * x;
+        out.mats[m].m = alpha;
+        out.mats[m].a2 = alpha * alpha;
+        out.mats[m].eta = d->model_param ? d->model_param[2 * (size_t)m + 1] : 0.0f;
+    }
     // triangle lights and their Materials (ModelRec n_models + k; cas is not read for them)
     out.tlights.assign((size_t)d->n_tri_lights, TriLightRec{});
     out.models.resize((size_t)n_models + (size_t)d->n_tri_lights);

@@ -24,6 +24,8 @@ struct HostScene {
     std::vector<ModelRec> models;
     std::vector<SphereRec> spheres;
     std::vector<LightRec> lights;
+    std::vector<MatRec> mats;            // one per ModelRec
+    bool general = false;                // non-Lambertian materials or triangle lights
     std::vector<TriLightRec> tlights;    // triangle lights (their Materials: models[n_models + k])
 };
 

@@ -17,6 +17,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 MAT_LAMBERTIAN = 1  # material::LAMBERTIAN, Material/Object.cuh:15
+MAT_FRESNEL, MAT_COOK, MAT_GGX, MAT_OREN_NAYAR = 7, 9, 17, 25   # Object.cuh:16-19
 QUAD_SPHERE = 0     # quadraticType::Sphere, Model/Model.cuh:100-103
 
 
@@ -91,7 +92,7 @@ class SceneDesc(C.Structure):
                 ("quad_type", _IP), ("n_point_lights", C.c_int32), ("pl_pos", _FP),
                 ("pl_illum", _FP), ("n_dir_lights", C.c_int32), ("dl_dir", _FP), ("dl_illum", _FP),
                 ("n_tri_lights", C.c_int32), ("tl_pos", _FP), ("tl_illum", _FP), ("tl_two_side", _IP),
-                ("tl_mat_type", _IP), ("tl_color", _FP)]
+                ("tl_mat_type", _IP), ("tl_color", _FP), ("model_param", _FP)]
 
 
 @dataclass
@@ -106,6 +107,8 @@ class SceneData:
     model_xf: np.ndarray = field(default_factory=lambda: np.zeros((0, 4, 4), np.float32))
     model_mat_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
     model_color: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    # (roughness, eta): second constructor argument of GGX / Cook_Torrance and of Fresnel (material.cuh:48,88,112)
+    model_param: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
     quad_coeff: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     quad_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
     pl_pos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
@@ -162,6 +165,9 @@ class SceneData:
         self.model_xf = _f32(self.model_xf, (nm, 4, 4))
         self.model_mat_type = _i32(self.model_mat_type, (nm,))
         self.model_color = _f32(self.model_color, (nm, 3))
+        if np.asarray(self.model_param).size != 2 * nm:
+            self.model_param = np.zeros((nm, 2), np.float32)
+        self.model_param = _f32(self.model_param, (nm, 2))
         self.pl_pos = _f32(self.pl_pos, (-1, 3))
         self.pl_illum = _f32(self.pl_illum, (-1, 3))
         self.dl_dir = _f32(self.dl_dir, (-1, 3))
@@ -190,6 +196,7 @@ class SceneData:
         d.mesh_first, d.mesh_count = ip(self.mesh_first), ip(self.mesh_count)
         d.model_xf, d.model_mat_type = fp(self.model_xf), ip(self.model_mat_type)
         d.model_color = fp(self.model_color)
+        d.model_param = fp(self.model_param)
         d.quad_coeff, d.quad_type = fp(self.quad_coeff), ip(self.quad_type)
         d.n_point_lights = int(self.pl_pos.shape[0])
         d.pl_pos, d.pl_illum = fp(self.pl_pos), fp(self.pl_illum)

@@ -361,4 +361,28 @@ def area_test_scene(seed=7):
     return scene.normalise(), rng
 
 
+def material_test_scene(seed=7):
+    """mixed_test_scene with one model per BRDF of material.cu: the backdrop
+    triangle Lambertian, the small triangle GGX, the blob Oren-Nayar, the ground Cook-Torrance, one
+    sphere GGX and one Fresnel glass (specular: paths through it skip sampleAllLight and pick up
+    light emission where they land); two point lights, one directional, one two-sided triangle
+    light."""
+    from .scene import MAT_COOK, MAT_FRESNEL, MAT_GGX, MAT_LAMBERTIAN, MAT_OREN_NAYAR
+    scene, rng = mixed_test_scene(seed)
+    #                       tri 0           tri 1    blob            ground    sphere 0  sphere 1
+    scene.model_mat_type = np.int32([MAT_LAMBERTIAN, MAT_GGX, MAT_OREN_NAYAR, MAT_COOK, MAT_GGX, MAT_FRESNEL])
+    scene.model_param = np.float32([[0, 0], [0.35, 0], [0, 0], [0.6, 0], [0.2, 0], [0, 1.5]])
+    scene.model_color[5] = (0.95, 0.95, 0.95)
+    scene.pl_pos = scene.pl_pos[:2].copy()
+    scene.pl_illum = (scene.pl_illum[:2] * 0.5).copy()
+    scene.dl_dir = np.float32([[0.6, -0.35, -0.7]])
+    scene.dl_illum = np.float32([[0.5, 0.45, 0.4]])
+    scene.tl_pos = np.float32([[(150.0, -60.0, -330.0), (190.0, 90.0, -350.0), (120.0, 60.0, -300.0)]])
+    scene.tl_illum = np.float32([[60.0, 90.0, 140.0]])
+    scene.tl_two_side = np.int32([1])
+    scene.tl_mat_type = np.int32([MAT_LAMBERTIAN])
+    scene.tl_color = np.float32([[0.5, 0.6, 0.9]])
+    return scene.normalise(), rng
+
+
 CONFIGS = {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}

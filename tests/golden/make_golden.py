@@ -41,13 +41,16 @@ CASES = {
     # (kernel.cu:268-313, camera kernel.cu:228-229) and the mixed scene under every light type
     "demo": (("demo", {}), 160, 120, (40, 20, 120, 100), [(2, 0), (4, 6)]),
     "area": (("area", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 5)]),
+    # every BRDF of material.cu, one model each
+    "materials": (("materials", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (3, 6)]),
 }
 
 
 SCENE_FIELDS = ["tri_pos", "tri_nrm", "tri_model", "mesh_first", "mesh_count", "model_xf",
                 "model_mat_type", "model_color", "quad_coeff", "quad_type", "pl_pos", "pl_illum"]
 OPTIONAL_SCENE_FIELDS = ["dl_dir", "dl_illum",        # absent from fixtures written before them
-                         "tl_pos", "tl_illum", "tl_two_side", "tl_mat_type", "tl_color"]
+                         "tl_pos", "tl_illum", "tl_two_side", "tl_mat_type", "tl_color",
+                         "model_param"]
 
 
 def load_case(name):
@@ -71,9 +74,9 @@ def load_case(name):
 
 def build_case(name):
     (kind, kw), w, h, crop, runs = CASES[name]
-    if kind in ("mixed", "sun", "area"):
+    if kind in ("mixed", "sun", "area", "materials"):
         scene, _ = {"mixed": scenes.mixed_test_scene, "sun": scenes.sun_test_scene,
-                    "area": scenes.area_test_scene}[kind]()
+                    "area": scenes.area_test_scene, "materials": scenes.material_test_scene}[kind]()
         cam = CameraArgs.for_image(w, h, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
     elif kind == "demo":
         scene = scenes.demo_scene()

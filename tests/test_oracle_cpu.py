@@ -214,3 +214,34 @@ def test_triangle_light_blocks_and_is_sampled():
     assert mean_floor([(down[::-1], False)]) == 0.0                          # faces up: L = BLACK
     blocker = [(-12.0, 4.0, 2.0), (12.0, 4.0, 2.0), (0.0, 4.0, -30.0)]       # one-sided, faces up, below the light
     assert mean_floor([(down, False), (blocker, False)]) < 0.02 * lit
+
+
+def test_rough2alpha_and_specular_emission():
+    """rough2alpha (material.cuh:7-13): log(1) = 0 leaves the constant term, and the clamp at 1e-3.
+    A Fresnel (specular) pane in front of a two-sided triangle light: its surface gathers no
+    direct light (PathTracer.cu:67-74), but the ray that leaves it picks up the light's emission
+    (PathTracer.cu:33-52) even at max_depth 0, where a Lambertian pane's last ray reads nothing."""
+    import ctypes as C
+    from raytracer_amd.scene import MAT_FRESNEL, SceneBuilder
+    f = orc.lib().orc_rough2alpha
+    f.argtypes, f.restype = [C.c_float], C.c_float
+    assert f(1.0) == np.float32(1.62142)
+    assert f(1e-9) == f(1e-3)
+    cam = CameraArgs.for_image(32, 24)
+    def centre(mat):
+        b = SceneBuilder()
+        b.add_triangle([(-30.0, -30.0, -8.0), (30.0, -30.0, -8.0), (0.0, 40.0, -8.0)], [(0.0, 0.0, 1.0)] * 3,
+                       color=(1.0, 1.0, 1.0))
+        b.add_triangle_light([(-60.0, -60.0, -20.0), (0.0, 80.0, -20.0), (60.0, -60.0, -20.0)], (3.0, 3.0, 3.0),
+                             two_side=True, color=(0.0, 0.0, 0.0))
+        s = b.build()
+        s.model_mat_type[:] = mat
+        s.model_param = np.float32([[0.0, 1.5]])
+        r = orc.render(s, cam, 32, 24, spp=16, max_depth=0, crop=(15, 11, 17, 13))
+        assert np.all(r["prim_id"] == 0)
+        return r["rgba"][..., :3].mean()
+    glass, matte = centre(MAT_FRESNEL), centre(1)
+    # (Fresnel::sample_f feeds |wo.y|, not 1 - |wo.y|, into Schlick's polynomial -- material.cuh:127-128 --
+    # so head-on rays almost always reflect; the few that refract carry the light's emission)
+    assert glass > 0.05
+    assert matte == 0.0           # the Lambertian front face cannot see the light behind it

@@ -464,7 +464,7 @@ def test_errors(gpu_ctx_factory):
         ctx.render(1, 0)
     assert e.value.code == abi.RT_ERR_STATE
     cfg = scenes.c1(8, 8)
-    cfg.scene.model_mat_type[:] = 17          # GGX: outside the hot path
+    cfg.scene.model_mat_type[:] = 5           # not a material::MATERIAL_TYPE (Object.cuh:13-21)
     with pytest.raises(abi.RtError) as e:
         ctx.upload_scene(cfg.scene)
     assert e.value.code == abi.RT_ERR_UNSUPPORTED
@@ -727,7 +727,7 @@ def test_full_size_c5_render(gpu_ctx_factory, c5_full):
 # ----------------------------------------------------------------------------- triangle lights (N3)
 def test_triangle_lights_full_frames(gpu_ctx_factory):
     """Scenes with TriangleLights (hit-able, emissive, sampled with MIS: Light.cu:35-105,
-    PathTracer.cu:33-52, Scene.cu:43-64,242-284) through k_path_area: whole frames against the
+    PathTracer.cu:33-52, Scene.cu:43-64,242-284) through k_path_general: whole frames against the
     oracle with ray counts, at depth 0 and with bounces off the lights' own surfaces; the tree
     and the scan agree bit for bit; rendering in two calls equals one."""
     scene, _ = scenes.area_test_scene()
@@ -787,3 +787,40 @@ def test_triangle_light_material_must_be_lambertian(gpu_ctx_factory):
     with pytest.raises(abi.RtError) as e:
         ctx.upload_scene(scene)
     assert e.value.code == abi.RT_ERR_UNSUPPORTED
+
+
+# ----------------------------------------------------------------------------- every BRDF (N4)
+def test_every_brdf_full_frames(gpu_ctx_factory):
+    """GGX, Cook-Torrance, Oren-Nayar and Fresnel (material.cu:84-254, material.cuh:108-164) next to
+    Lambertian, under point, directional and triangle lights: whole frames against the oracle with
+    ray counts, at depth 0 (the Fresnel sphere's last ray is traced for the light it may land on)
+    and with bounces; tree == scan bit for bit; two calls == one."""
+    scene, _ = scenes.material_test_scene()
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    for spp, depth in [(2, 0), (3, 6)]:
+        got, ref, st = render_both(gpu_ctx_factory, scene, cam, 96, 64, spp, depth)
+        check_images(got, ref, st)
+        assert st.batch_launches == 0
+    for model_prims in (range(0, 1), range(1, 2), range(2, 282), range(282, 408), range(408, 409), range(409, 410)):
+        seen = np.isin(got["prim_id"], list(model_prims))
+        assert seen.sum() > 20 and got["rgba"][..., :3][seen].max() > 0        # every material is in view and lit
+    ctx = gpu_ctx_factory(96, 64)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    ctx.set_culling(0)
+    ctx.render(1, 6)
+    ctx.render(2, 6)
+    scan = ctx.read_framebuffer()
+    assert np.array_equal(scan["rgba"].view(np.uint32), got["rgba"].view(np.uint32))
+
+
+def test_material_parameters_are_required(gpu_ctx_factory):
+    from raytracer_amd.scene import SceneDesc
+    import ctypes as C
+    cfg = scenes.c1(8, 8)
+    cfg.scene.model_mat_type[:] = 17
+    d = cfg.scene.desc()
+    d.model_param = C.POINTER(C.c_float)()                   # GGX without its roughness
+    ctx = gpu_ctx_factory(8, 8)
+    rc = abi.lib().rt_upload_scene(ctx._h, C.byref(d))
+    assert rc == abi.RT_ERR_INVALID

@@ -138,7 +138,7 @@ struct Stamps {
         if ((threadIdx.x & 63u) == 0) {
             const int b = cost ? 32 - __builtin_clz(cost) : 0;
             atomicAdd(&g_stamps[3][b > 15 ? 15 : b], 1ull);
-            atomicAdd(&g_stamps[0][b > 15 ? 15 : b], d);         // (row 0 is free: k_primary is gone)
+            atomicAdd(&g_stamps[0][b > 15 ? 15 : b], d);         // (row 0 holds no kernel's stamps)
         }
     }
     // close the segment that began at the previous mark and charge it to `seg`

@@ -188,8 +188,8 @@ def test_heavy_chunk_feedback_and_cooperative_form(gpu_ctx_factory):
 
 
 def test_depth0_pipeline_on_small_deep_tree(gpu_ctx_factory):
-    """render(2, 0) three times over the same deep tree: the batch pipeline (k_primary ->
-    k_primary_hard -> k_shadow) in batches of two, against the oracle and the plain scan."""
+    """render(2, 0) three times over the same deep tree: the batch kernel (k_batch: phases P,
+    H, S of a unit) in batches of two, against the oracle and the plain scan."""
     cfg = scenes.c3(256, 144, f=12, ground=(10, 6))
     ctx = gpu_ctx_factory(256, 144)
     ctx.upload_scene(cfg.scene)
@@ -230,7 +230,7 @@ def flicker_scene(rng, n_tris):
 @pytest.mark.parametrize("spp", [16, 21, 70, 140])
 def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
     """rt_render(n, 0) over a deep tree traces all samples of a batch at once from PREDICTED
-    RNG counters and settles mispredicted pixels by enumeration (k_primary, k_primary_hard).
+    RNG counters and settles mispredicted pixels by enumeration (phases P and H of k_batch).
     Batches are of 16 samples, of 32 from 64 samples on (70 = 32 + 32 + 6), of 64 from 128 on
     (140 = 64 + 64 + 12).
     On a scene built to defeat the prediction it must equal (a) the oracle, (b) the same
@@ -266,7 +266,7 @@ def test_sample_batches_on_flickering_pixels(gpu_ctx_factory, spp):
     hit = out[0]["prim_id"] >= 0
     assert 0.15 < hit.mean() < 0.85                     # the last sample's hits: a coin flip per pixel
     # the oracle at every batch shape: 16 (8 px x 16), 21 = 16 + 5, 70 = 32 + 32 + 6 (4 px x 32,
-    # k_primary_hard's four rounds), 140 = 64 + 64 + 12 (2 px x 64, eight rounds)
+    # the enumeration's four rounds), 140 = 64 + 64 + 12 (2 px x 64, eight rounds)
     ref = orc.render(scene, cam, 80, 48, spp=spp, max_depth=0)
     check_images(out[0], ref, stats[0])
 
@@ -657,8 +657,8 @@ def c5_full():
 
 
 def test_full_size_c4_render(gpu_ctx_factory, c4_full):
-    """C4 at its full size (871 414 triangles, 3840x2160) through rt_render: k_primary /
-    k_primary_hard / k_shadow over the real tree.  (a) 2 spp against the oracle on windows at
+    """C4 at its full size (871 414 triangles, 3840x2160) through rt_render: k_batch
+    over the real tree.  (a) 2 spp against the oracle on windows at
     the silhouette, on the mesh, the ground and the sky; (b) a 32-sample batch (the shape the
     bench runs) equals the same 32 samples rendered one call at a time, in every bit of the
     image, id and t buffers and in the shadow-ray count."""

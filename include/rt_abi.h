@@ -44,8 +44,8 @@ typedef struct rt_context rt_context;
  * Point and directional lights (the delta lights, Scene.cu:93-102) and triangle lights
  * (hit-able area lights: Scene.cu:43-64, emission core/PathTracer.cu:33-52, the MIS branch
  * Scene.cu:242-284) are supported; a scene with triangle lights renders through the general
- * path kernel, not the depth-0 batch kernel.  Environment lights (light_size[3]) are outside
- * the path and have no fields here.
+ * path kernel, not the depth-0 batch kernel; so does one with an environment light
+ * (Light.cu:137-234, PiecewiseConstant.cu; at most one, as Scene::getEnvironmentLight reads).
  * A light hit reports prim_id = n_tris + n_quads + its index. */
 typedef struct rt_scene_desc {
     int32_t n_tri_models;          /* model_size[0]                               */
@@ -80,6 +80,10 @@ typedef struct rt_scene_desc {
     const float *model_param;      /* [n_models][2] (roughness, eta): the second constructor argument of
                                       GGX / Cook_Torrance (material.cuh:48,88) and of Fresnel (:112);
                                       may be NULL when every model is LAMBERTIAN or Oren_Nayar */
+    int32_t n_env_lights;          /* light_size[3]: 0 or 1                        */
+    int32_t env_width, env_height;
+    const float *env_image;        /* [env_height][env_width][4] floats, as stbi_loadf(.., 4) hands them to
+                                      EnvironmentLight(texture, w, h) (kernel.cu:271-272, Light.cuh:108) */
 } rt_scene_desc;
 
 /* Camera(pos, lookat, fov, near, far, int2 res, up)          (Camera/Camera.cuh:11).

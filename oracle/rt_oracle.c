@@ -866,6 +866,169 @@ static f3 eval_direct_delta(const orc_scene *s, int type, int j, rec_t rec, orc_
 
 #define POWER_HEURISTIC(x, y) ((x) * (x) / ((x) * (x) + (y) * (y)))   /* Scene/Scene.cuh:5-7 */
 
+/* ---------------------------------------------------------------- EnvironmentLight */
+/* PiecewiseConstant/PiecewiseConstant.cu:8-22 Distribution::Distribution */
+typedef struct { int n; float *value, *cdf; float funInt; } dist1_t;
+static void dist1_make(dist1_t *d, int n, const float *v)
+{
+    d->n = n;
+    d->value = (float *)malloc(sizeof(float) * (size_t)n);
+    memcpy(d->value, v, sizeof(float) * (size_t)n);
+    d->cdf = (float *)malloc(sizeof(float) * (size_t)(n + 1));
+    d->cdf[0] = 0.0f;
+    for (int i = 1; i <= n; i++)
+        d->cdf[i] = d->cdf[i - 1] + d->value[i - 1] / n;
+    d->funInt = d->cdf[n];
+    for (int i = 1; i <= n; i++)
+        d->cdf[i] = d->funInt == 0 ? (float)i / n : d->cdf[i] / d->funInt;
+    d->cdf[n] = 1.0f;
+}
+/* PiecewiseConstant.cu:24-40 Distribution::sample: the search as written (it can stop one
+ * interval early), and the return value is offset + fraction, NOT divided by n */
+static float dist1_sample(const dist1_t *d, float u, float *pdf, int *offset)
+{
+    int l = 0, r = d->n;
+    int mid;
+    while (r > l) {
+        mid = l + (r - l) / 2;
+        if (d->cdf[mid] > u)
+            r = mid - 1;
+        else
+            l = mid + 1;
+    }
+    if (r == d->n)
+        --r;
+    if (r < 0)
+        r = 0;                       /* (cannot happen for u > 0: cdf[0] = 0) */
+    *offset = r;
+    *pdf = d->value[r] / d->funInt;
+    return d->cdf[r + 1] == d->cdf[r] ? r : r + (u - d->cdf[r]) / (d->cdf[r + 1] - d->cdf[r]);
+}
+/* PiecewiseConstant.cu:65-96 Distribution2D::Distribution2D; rgb2y_xyz :3-6 (0.06007 is a double) */
+typedef struct { int width, height; dist1_t *cond; dist1_t marg; float funInt; const float *img; } env_t;
+static env_t *env_make(const float *img, int w, int h)
+{
+    env_t *e = (env_t *)malloc(sizeof(env_t));
+    e->width = w; e->height = h; e->img = img;
+    e->funInt = 0.0f;
+    float *v_tmp = (float *)malloc(sizeof(float) * (size_t)h);
+    float *ctmp = (float *)malloc(sizeof(float) * (size_t)w);
+    e->cond = (dist1_t *)malloc(sizeof(dist1_t) * (size_t)h);
+    for (int i = 0; i < h; i++) {
+        for (int j = 0; j < w; j++) {
+            size_t idx = 4 * ((size_t)i * w + j);
+            float tmp = (float)((double)(img[idx] + 4.5906f * img[idx + 1]) + 0.06007 * (double)img[idx + 2]);
+            ctmp[j] = tmp;
+            e->funInt += tmp;
+        }
+        dist1_make(&e->cond[i], w, ctmp);
+        v_tmp[i] = e->cond[i].funInt;
+    }
+    e->funInt /= w * h;
+    dist1_make(&e->marg, h, v_tmp);
+    free(v_tmp);
+    free(ctmp);
+    return e;
+}
+static void env_free(env_t *e)
+{
+    if (!e) return;
+    for (int i = 0; i < e->height; i++) { free(e->cond[i].value); free(e->cond[i].cdf); }
+    free(e->cond); free(e->marg.value); free(e->marg.cdf); free(e);
+}
+/* PiecewiseConstant.cu:108-118 */
+static f2 env_dist_sample(const env_t *e, f2 u, float *pdf)
+{
+    float pdfs[2];
+    int v;
+    float d1 = dist1_sample(&e->marg, u.y, pdfs + 1, &v);
+    float d0 = dist1_sample(&e->cond[v], u.x, pdfs, &v);
+    *pdf = pdfs[0] * pdfs[1];
+    f2 r = { d0, d1 };
+    return r;
+}
+/* PiecewiseConstant.cu:98-106 Distribution2D::PDF.  H12: an index that reaches n (phi = 2 pi,
+ * theta = pi after rounding) reads past the arrays in the reference; clamped to n - 1 here. */
+static float env_dist_pdf(const env_t *e, f2 sample)
+{
+    int i1 = (int)(e->width * sample.x);
+    int i2 = (int)(e->height * sample.y);
+    if (i1 < 0) i1 = 0;
+    if (i2 < 0) i2 = 0;
+    if (i1 > e->width - 1) i1 = e->width - 1;
+    if (i2 > e->height - 1) i2 = e->height - 1;
+    return e->cond[i2].value[i1] / e->marg.funInt;
+}
+/* tex2D<float4>(img, x, y) of Light.cu:153,197 with the texture object of Light.cu:224-232:
+ * normalised coordinates, wrap addressing, linear filtering.  H11: restated from the CUDA
+ * programming guide's texture-fetching appendix -- xB = x W - 0.5, i = floor(xB), alpha = frac(xB)
+ * kept in 9-bit fixed point with 8 fractional bits (rounded to nearest here), texels wrapped. */
+static f3 env_tex2d(const env_t *e, float x, float y)
+{
+    float xb = (x - floorf(x)) * (float)e->width - 0.5f, yb = (y - floorf(y)) * (float)e->height - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = floorf((xb - fi) * 256.0f + 0.5f) / 256.0f, b = floorf((yb - fj) * 256.0f + 0.5f) / 256.0f;
+    int i0 = (int)fi, j0 = (int)fj;
+    int i[2] = { ((i0 % e->width) + e->width) % e->width, (((i0 + 1) % e->width) + e->width) % e->width };
+    int j[2] = { ((j0 % e->height) + e->height) % e->height, (((j0 + 1) % e->height) + e->height) % e->height };
+    float out[3];
+    for (int c = 0; c < 3; c++) {
+        float t00 = e->img[4 * ((size_t)j[0] * e->width + i[0]) + c], t10 = e->img[4 * ((size_t)j[0] * e->width + i[1]) + c];
+        float t01 = e->img[4 * ((size_t)j[1] * e->width + i[0]) + c], t11 = e->img[4 * ((size_t)j[1] * e->width + i[1]) + c];
+        out[c] = (1 - a) * (1 - b) * t00 + a * (1 - b) * t10 + (1 - a) * b * t01 + a * b * t11;
+    }
+    return mk3(out[0], out[1], out[2]);
+}
+#define ENV_INV_PI 0.3183098861837907f          /* Light/Light.cu:2-4 */
+static float m_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+/* Light/Light.cu:180-199 EnvironmentLight::L (getLe(r) = L(r.dir), :175-178) */
+static f3 env_L(const env_t *e, f3 r)
+{
+    f3 k = normalize3(r);
+    float phi = 0.0f;
+    float theta = m_acosf(k.y);
+    float sint = m_sinf(theta);
+    if (sint > 0.001f) {
+        phi = m_atan2f(r.x, r.z);
+        if (r.z < 0.0f)
+            phi = (float)((double)phi + ORC_PI_D);
+        if (phi < 0.0f)
+            phi = (float)((double)phi + (double)2.0f * ORC_PI_D);
+    }
+    return env_tex2d(e, phi * ENV_INV_PI * 0.5f, theta * ENV_INV_PI);
+}
+/* Light/Light.cu:157-173 EnvironmentLight::PDF */
+static float env_pdf(const env_t *e, f3 wi)
+{
+    f3 k = normalize3(wi);
+    float theta = m_acosf(k.y);
+    float sint = m_sinf(theta);
+    float phi = m_atan2f(k.x, k.z);
+    if (sint < 0.001f)
+        return 0.0f;
+    if (wi.z < 0.0f)
+        phi = (float)((double)phi + ORC_PI_D);
+    if (phi < 0.0f)
+        phi = (float)((double)phi + (double)2.0f * ORC_PI_D);
+    f2 sm = { phi * 0.5f * ENV_INV_PI, theta * ENV_INV_PI };
+    return (float)((double)env_dist_pdf(e, sm) / ((double)2.0f * ORC_PI_D * ORC_PI_D * (double)sint));
+}
+
+/* The tables EnvironmentLight::setUp (Light.cu:201-234) builds once on the host: built at the
+ * entry of every API call that renders (env_begin) and dropped at its end (test infrastructure:
+ * one call at a time). */
+static env_t *g_env_cur = NULL;
+static void env_begin(const orc_scene *s)
+{
+    g_env_cur = (s->n_env_lights > 0 && s->env_image) ? env_make(s->env_image, s->env_width, s->env_height) : NULL;
+}
+static void env_end(void)
+{
+    env_free(g_env_cur);
+    g_env_cur = NULL;
+}
+static const env_t *scene_env(const orc_scene *s) { return s->n_env_lights > 0 ? g_env_cur : NULL; }
+
 /* Scene/Scene.cu:205-287 evaluateDirectLight for triangle light k (isDelta = false, idx = k),
  * with TriangleLight::lightIllumi (Light/Light.cu:47-65) inlined.  rec is by value. */
 static f3 eval_direct_area(const orc_scene *s, int k, rec_t rec, f2 sample_light, f2 sample_brdf,
@@ -924,6 +1087,74 @@ static f3 eval_direct_area(const orc_scene *s, int k, rec_t rec, f2 sample_light
         if (scene_hit(s, &r, &rec) && rec.lightidx == idx)          /* :275 */
             lc = tl_L(&l, neg3(wi));                                /* :277 */
         /* else getLe(r) = BLACK (Light.cuh:94) */
+        res = add3(res, div3s(scale3(mul3(lc, f), weight), rec.pdf_surface));   /* :282 */
+    }
+    return res;
+}
+
+/* Scene/Scene.cu:205-287 evaluateDirectLight for the environment light (isDelta = false,
+ * idx = n_tri_lights + j, Scene.cu:109-114), EnvironmentLight::lightIllumi (Light.cu:137-155)
+ * inlined.  H10: `Ray r;` (Scene.cu:207) is default-constructed (Ray.cuh:16) and lightIllumi keeps
+ * its origin (Light.cu:142), so lpos (Scene.cu:213) is uninitialised: restated as (0, 0, 0). */
+static int scene_hit(const orc_scene *s, const ray_t *r, rec_t *rec);
+static f3 eval_direct_env(const orc_scene *s, const env_t *e, rec_t rec, f2 sample_light, f2 sample_brdf,
+                          orc_counts *cnt)
+{
+    const int idx = s->n_tri_lights;                                /* Scene.cu:111, j = 0 */
+    f3 color;
+    ray_t r;
+    {   /* lightIllumi */
+        f2 sm = env_dist_sample(e, sample_light, &rec.pdf_light);   /* Light.cu:139 */
+        float theta = (float)((double)sm.y * ORC_PI_D), phi = (float)((double)(2.0f * sm.x) * ORC_PI_D);   /* :140 */
+        float sint = m_sinf(theta);                                 /* :141 */
+        r = mk_ray(mk3(0.0f, 0.0f, 0.0f),                           /* :142, H10 */
+                   mk3(m_sinf(theta) * m_sinf(phi), m_cosf(theta), m_sinf(theta) * m_cosf(phi)));
+        if (rec.pdf_light < 0.001f)                                 /* :143-147 */
+            color = mk3(0.0f, 0.0f, 0.0f);
+        else if (sint < 0.001f)
+            color = mk3(0.0f, 0.0f, 0.0f);
+        else {
+            rec.pdf_light = (float)((double)rec.pdf_light / ((double)(2.0f * sint) * ORC_PI_D * ORC_PI_D));   /* :149 */
+            color = env_tex2d(e, 0.5f * phi * ENV_INV_PI, theta * ENV_INV_PI);   /* :153 */
+        }
+    }
+    f3 lpos = r.o;                                                  /* Scene.cu:213 */
+    rec_t light_rec;
+    rec_init(&light_rec);
+    int blocked = 0;
+    r = rec_spawn_ray(&rec, neg3(r.d));                             /* :218 */
+    f3 f = scale3(rec_f(s, &rec, neg3(rec.wo.d), r.d), fabsf(dot3(rec.normal, r.d))); /* :222 */
+    if (!is_black(f)) {                                             /* :224 */
+        cnt->shadow++;
+        if (scene_hit(s, &r, &light_rec))                           /* :225-228; a triangle light's index never equals idx */
+            blocked = light_rec.lightidx == idx
+                          ? 0
+                          : (length3(sub3(light_rec.pos, r.o)) < length3(sub3(r.o, lpos)) - 0.01f);
+    }
+    f3 res = mk3(0.0f, 0.0f, 0.0f);
+    if (rec.pdf_light < 0.001f)                                     /* :233 */
+        return mk3(0.0f, 0.0f, 0.0f);
+    if (!is_black(f) && !blocked && !is_black(color)) {             /* :236 */
+        rec.pdf_surface = rec_pdf(s, &rec, neg3(rec.wo.d), r.d);    /* :244 */
+        float weight = POWER_HEURISTIC(rec.pdf_light, rec.pdf_surface);   /* :245 */
+        weight /= rec.pdf_light;                                    /* :246 */
+        color = scale3(mul3(color, f), weight);                     /* :247 */
+        res = color;
+    }
+    f3 wi = mk3(0.0f, 0.0f, 0.0f);                                  /* :253 uninitialised: H9 */
+    float weight = 1.0f;
+    f = rec_sample_f(s, &rec, neg3(rec.wo.d), &wi, &rec.pdf_surface, sample_brdf);   /* :258 */
+    f = scale3(f, fabsf(dot3(rec.normal, wi)));                     /* :259 */
+    r = rec_spawn_ray(&rec, wi);                                    /* :260 */
+    if (!is_black(f) && rec.pdf_surface > 0.001f) {                 /* :264 */
+        float pdf = env_pdf(e, wi);                                 /* :268 */
+        if (fabsf(pdf) < 0.01f)                                     /* :269 */
+            return res;
+        weight = POWER_HEURISTIC(rec.pdf_surface, pdf);             /* :271 */
+        /* :275-280: hit(r, rec) is evaluated, but rec.lightidx can never equal idx (only triangle
+         * lights set it, to indices below n_tri_lights), so l = getLe(r) whether or not the ray
+         * is blocked; the trace has no other effect and is not restated */
+        f3 lc = env_L(e, r.d);
         res = add3(res, div3s(scale3(mul3(lc, f), weight), rec.pdf_surface));   /* :282 */
     }
     return res;
@@ -1022,6 +1253,13 @@ static f3 sample_all_light(const orc_scene *s, const rec_t *rec, rng_t *g, orc_c
         f2 sample_light = { tmp[0], tmp[1] }, sample_surface = { tmp[2], tmp[3] };
         res = add3(res, eval_direct_area(s, j, *rec, sample_light, sample_surface, cnt));
     }
+    const env_t *e = scene_env(s);
+    for (int j = 0; e && j < s->n_env_lights; j++) {        /* light::ENVIRONMENT_LIGHT (one at most) */
+        float tmp[4];
+        rng_uniform4(g, tmp);
+        f2 sample_light = { tmp[0], tmp[1] }, sample_surface = { tmp[2], tmp[3] };
+        res = add3(res, eval_direct_env(s, e, *rec, sample_light, sample_surface, cnt));
+    }
     return res;
 }
 
@@ -1040,7 +1278,8 @@ static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_
         rng_uniform4(g, tmp);                                       /* :27 */
         f2 sample_scatter = { tmp[0], tmp[1] };
         rec_init(&rec);                                             /* :29 */
-        if (bounces > max_depth && !(specular_bounce && s->n_tri_lights > 0)) {
+        const env_t *env = scene_env(s);
+        if (bounces > max_depth && !(specular_bounce && (s->n_tri_lights > 0 || env))) {
             /* :31 traces this ray too, but nothing reads the result before the break at :64
              * unless the ray left a specular surface and there is a light to land on (:33-52). */
             break;
@@ -1055,12 +1294,14 @@ static f3 path_tracer(const orc_scene *s, ray_t r, rng_t *g, int max_depth, orc_
         }
         rec.wo = r;                                                 /* :32 */
         /* :33-52 emission of a triangle light the camera ray, or a ray off a specular surface,
-         * lands on; :53-61 environment light: out of scope */
+         * lands on */
         if ((bounces == 0 || specular_bounce) && ishit && rec.isLight &&
             rec.light_type >= ORC_LIGHT_TRIANGLE && rec.lightidx >= 0 && rec.lightidx < s->n_tri_lights) {
             tl_t l = tl_load(s, rec.lightidx);
             res = add3(res, mul3(beta, tl_L(&l, neg3(r.d))));       /* :47 */
         }
+        if ((bounces == 0 || specular_bounce) && !ishit && env)     /* :53-61 */
+            res = add3(res, mul3(beta, env_L(env, r.d)));
         if (!ishit || bounces > max_depth)                          /* :64 */
             break;
         specular_bounce = rec.material_type & ORC_MAT_SPECULAR_BIT; /* :67 */
@@ -1131,6 +1372,7 @@ int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int widt
         y0 >= y1 || spp < 1)
         return -1;
     cam_t cam = cam_make(cam_args);
+    env_begin(scene);
     int cw = x1 - x0, ch = y1 - y0;
     uint64_t n_primary = 0, n_shadow = 0, n_bounce = 0;
 #ifdef _OPENMP
@@ -1156,6 +1398,7 @@ int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int widt
         counts->shadow = n_shadow;
         counts->bounce = n_bounce;
     }
+    env_end();
     return 0;
 }
 
@@ -1172,6 +1415,7 @@ int orc_render_pixels(const orc_scene *scene, const orc_camera_args *cam_args, i
         if (xy[2 * i] < 0 || xy[2 * i] >= width || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= height)
             return -1;
     cam_t cam = cam_make(cam_args);
+    env_begin(scene);
     uint64_t n_primary = 0, n_shadow = 0, n_bounce = 0;
 #ifdef _OPENMP
     if (threads > 0)
@@ -1194,6 +1438,7 @@ int orc_render_pixels(const orc_scene *scene, const orc_camera_args *cam_args, i
         counts->shadow = n_shadow;
         counts->bounce = n_bounce;
     }
+    env_end();
     return 0;
 }
 
@@ -1239,10 +1484,12 @@ int orc_trace_ray(const orc_scene *scene, const float org[3], const float dir[3]
         return -1;
     ray_t r = mk_ray(mk3(org[0], org[1], org[2]), mk3(dir[0], dir[1], dir[2]));
     rng_t g = { pixel_index, draw0 };
+    env_begin(scene);
     orc_counts c = { 0, 0, 0 };
     float ft = ORC_INF;
     int fp = -1;
     f3 col = path_tracer(scene, r, &g, max_depth, &c, &ft, &fp);
+    env_end();
     rgb[0] = col.x; rgb[1] = col.y; rgb[2] = col.z;
     if (t) *t = ft;
     if (prim) *prim = fp;

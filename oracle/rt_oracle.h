@@ -69,6 +69,10 @@ typedef struct orc_scene {
     const float *tl_color;    /* [n_tri_lights][3]    Lambertian::color of Material[n_models + k] */
     const float *model_param; /* [n_models][2] (roughness, eta): the second constructor argument of GGX /
                                  Cook_Torrance (material.cuh:48,88) and of Fresnel (:112); NULL = zeros */
+    int32_t n_env_lights;     /* light_size[3]: 0 or 1 */
+    int32_t env_width, env_height;
+    const float *env_image;   /* [env_height][env_width][4] floats, as stbi_loadf(.., 4) hands them to
+                                 EnvironmentLight(texture, w, h) (kernel.cu:271-272, Light.cuh:108) */
 } orc_scene;
 
 /* The 7 constructor arguments of Camera (reference Camera/Camera.cuh:11). */

@@ -115,6 +115,7 @@ struct rt_context {
     // depth 0 over a deep tree (k_batch, rt_kernels.hip): samples per batch
     int batch_wanted = 0;                // RT_BATCH: samples per k_batch launch (0: chosen by the call's sample count)
     uint64_t batch_launches = 0;         // launches of k_batch
+    int batch_min_top = 3;               // k_batch from this tree height on (RT_BATCH_MIN_TOP)
     bool feedback_debug = false;
     bool batch_feedback = true;          // costly units of one launch go out first, by pixel, in the next (RT_FEEDBACK=0: off)
 
@@ -430,6 +431,7 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     }
     if (const char *e = std::getenv("RT_BATCH")) c->batch_wanted = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_FEEDBACK")) c->batch_feedback = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RT_BATCH_MIN_TOP")) c->batch_min_top = std::atoi(e);
     if (const char *e = std::getenv("RT_FEEDBACK_DEBUG")) c->feedback_debug = std::atoi(e) != 0;
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
@@ -502,6 +504,25 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     RT_HIP(c, up(mats, hs.mats.data(), hs.mats.size() * sizeof(MatRec)));
     v.tlights = tlights;
     v.n_tlights = (int)hs.tlights.size();
+    v.env = EnvView{};
+    if (hs.env_n) {
+        float4 *eimg = nullptr; float *cv = nullptr, *cc = nullptr, *cf = nullptr, *mv = nullptr, *mc = nullptr;
+        if ((rc = dalloc(c, c->scene_allocs, eimg, hs.env_img.size() / 4))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, cv, hs.env_cond_value.size()))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, cc, hs.env_cond_cdf.size()))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, cf, hs.env_cond_funint.size()))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, mv, hs.env_marg_value.size()))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, mc, hs.env_marg_cdf.size()))) return rc;
+        RT_HIP(c, up(eimg, hs.env_img.data(), hs.env_img.size() * sizeof(float)));
+        RT_HIP(c, up(cv, hs.env_cond_value.data(), hs.env_cond_value.size() * sizeof(float)));
+        RT_HIP(c, up(cc, hs.env_cond_cdf.data(), hs.env_cond_cdf.size() * sizeof(float)));
+        RT_HIP(c, up(cf, hs.env_cond_funint.data(), hs.env_cond_funint.size() * sizeof(float)));
+        RT_HIP(c, up(mv, hs.env_marg_value.data(), hs.env_marg_value.size() * sizeof(float)));
+        RT_HIP(c, up(mc, hs.env_marg_cdf.data(), hs.env_marg_cdf.size() * sizeof(float)));
+        v.env.img = (const float *)eimg; v.env.cond_value = cv; v.env.cond_cdf = cc; v.env.cond_funint = cf;
+        v.env.marg_value = mv; v.env.marg_cdf = mc; v.env.marg_funint = hs.env_marg_funint;
+        v.env.w = hs.env_w; v.env.h = hs.env_h; v.env.n = 1;
+    }
     v.mats = mats;
     v.general = hs.general ? 1 : 0;
     v.tris = tris; v.tri_pos_of = pos_of; v.tri_cold = cold; v.models = models;
@@ -575,7 +596,7 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
     if (n_samples < 0 || max_depth < 0) return fail(c, RT_ERR_INVALID, "n_samples and max_depth must be >= 0");
     RT_HIP(c, hipSetDevice(c->device));
     hipStream_t s0 = c->stream;
-    if (max_depth == 0 && c->v.cull && c->v.tree.top >= 3 && !c->v.general) {
+    if (max_depth == 0 && c->v.cull && c->v.tree.top >= c->batch_min_top && !c->v.general) {
         // Depth 0 over a deep tree, one kernel per batch of samples and lane (k_batch,
         // rt_kernels.hip): camera rays from predicted counters, shadow rays and the running mean
         // of a unit without leaving the wave.  The lanes' launches follow each other on their own

@@ -724,6 +724,99 @@ __device__ __forceinline__ v3 brdf_sample_f(const Hit &h, const ModelRec &M, con
     return res;
 }
 
+// ------------------------------------------------------------------ EnvironmentLight (general kernel)
+__device__ __forceinline__ float m_atan2f(float y, float x) { return (float)atan2((double)y, (double)x); }
+constexpr double kPiD = 3.14159265358979323846;
+constexpr float kEnvInvPi = 0.3183098861837907f;                                  // Light/Light.cu:2-4
+// Distribution::sample (PiecewiseConstant.cu:24-40): the search as written, and the return value is
+// offset + fraction, not divided by n
+__device__ __forceinline__ float dist1_sample(const float *value, const float *cdf, float funint, int n,
+                                              float u, float &pdf, int &offset)
+{
+    int l = 0, r = n;
+    while (r > l) {
+        const int mid = l + (r - l) / 2;
+        if (cdf[mid] > u)
+            r = mid - 1;
+        else
+            l = mid + 1;
+    }
+    if (r == n)
+        --r;
+    if (r < 0)
+        r = 0;
+    offset = r;
+    pdf = value[r] / funint;
+    return cdf[r + 1] == cdf[r] ? (float)r : (float)r + (u - cdf[r]) / (cdf[r + 1] - cdf[r]);
+}
+// Distribution2D::sample (PiecewiseConstant.cu:108-118)
+__device__ __forceinline__ void env_dist_sample(const EnvView &e, float ux, float uy, float &d0, float &d1, float &pdf)
+{
+    float p0, p1;
+    int v;
+    d1 = dist1_sample(e.marg_value, e.marg_cdf, e.marg_funint, e.h, uy, p1, v);
+    d0 = dist1_sample(e.cond_value + (size_t)v * e.w, e.cond_cdf + (size_t)v * (e.w + 1), e.cond_funint[v], e.w, ux, p0, v);
+    pdf = p0 * p1;
+}
+// Distribution2D::PDF (PiecewiseConstant.cu:98-106); H12: indices clamped to the arrays
+__device__ __forceinline__ float env_dist_pdf(const EnvView &e, float sx, float sy)
+{
+    int i1 = (int)(e.w * sx), i2 = (int)(e.h * sy);
+    i1 = min(max(i1, 0), e.w - 1);
+    i2 = min(max(i2, 0), e.h - 1);
+    return e.cond_value[(size_t)i2 * e.w + i1] / e.marg_funint;
+}
+// tex2D<float4>(img, x, y) under the texture object of Light.cu:224-232 (normalised coordinates,
+// wrap, linear): hazard H11, the filter of the CUDA programming guide restated in software
+__device__ __forceinline__ v3 env_tex2d(const EnvView &e, float x, float y)
+{
+    float xb = (x - floorf(x)) * (float)e.w - 0.5f, yb = (y - floorf(y)) * (float)e.h - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = floorf((xb - fi) * 256.0f + 0.5f) / 256.0f, b = floorf((yb - fj) * 256.0f + 0.5f) / 256.0f;
+    int i0 = (int)fi, j0 = (int)fj;
+    int i[2] = {((i0 % e.w) + e.w) % e.w, (((i0 + 1) % e.w) + e.w) % e.w};
+    int j[2] = {((j0 % e.h) + e.h) % e.h, (((j0 + 1) % e.h) + e.h) % e.h};
+    const float4 *img = (const float4 *)e.img;
+    const float4 t00 = img[(size_t)j[0] * e.w + i[0]], t10 = img[(size_t)j[0] * e.w + i[1]];
+    const float4 t01 = img[(size_t)j[1] * e.w + i[0]], t11 = img[(size_t)j[1] * e.w + i[1]];
+    auto mix = [&](float c00, float c10, float c01, float c11) {
+        return (1 - a) * (1 - b) * c00 + a * (1 - b) * c10 + (1 - a) * b * c01 + a * b * c11;
+    };
+    return mk3(mix(t00.x, t10.x, t01.x, t11.x), mix(t00.y, t10.y, t01.y, t11.y), mix(t00.z, t10.z, t01.z, t11.z));
+}
+// EnvironmentLight::L (Light.cu:180-199); getLe(r) = L(r.dir)
+__device__ __forceinline__ v3 env_L(const EnvView &e, v3 r)
+{
+    v3 k = normalize(r);
+    float phi = 0.0f;
+    float theta = m_acosf(k.y);
+    float sint = m_sinf(theta);
+    if (sint > 0.001f) {
+        phi = m_atan2f(r.x, r.z);
+        if (r.z < 0.0f)
+            phi = (float)((double)phi + kPiD);
+        if (phi < 0.0f)
+            phi = (float)((double)phi + (double)2.0f * kPiD);
+    }
+    return env_tex2d(e, phi * kEnvInvPi * 0.5f, theta * kEnvInvPi);
+}
+// EnvironmentLight::PDF (Light.cu:157-173)
+__device__ __forceinline__ float env_pdf(const EnvView &e, v3 wi)
+{
+    v3 k = normalize(wi);
+    float theta = m_acosf(k.y);
+    float sint = m_sinf(theta);
+    float phi = m_atan2f(k.x, k.z);
+    if (sint < 0.001f)
+        return 0.0f;
+    if (wi.z < 0.0f)
+        phi = (float)((double)phi + kPiD);
+    if (phi < 0.0f)
+        phi = (float)((double)phi + (double)2.0f * kPiD);
+    return (float)((double)env_dist_pdf(e, phi * 0.5f * kEnvInvPi, theta * kEnvInvPi) /
+                   ((double)2.0f * kPiD * kPiD * (double)sint));
+}
+
 // black(x) = length(x) < 0.001f (Scene.cu:3-5) and the `length(f) < 0.0001f` of PathTracer.cu:77, without the
 // square root: sqrtf is correctly rounded and monotone, so sqrtf(y) < c holds exactly for the y below
 // the smallest float whose root reaches c -- 0x1.0c6f7ap-20 for c = 0.001f, 0x1.5798ecp-27 for

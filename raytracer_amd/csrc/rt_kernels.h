@@ -102,6 +102,7 @@ struct DevView {
     const SphereRec *spheres;
     const LightRec *lights;         // delta lights (point, then directional)
     const TriLightRec *tlights;     // triangle lights: hit-able (Scene.cu:43-64), sampled with MIS (Scene.cu:242-284)
+    EnvView env;                    // the environment light (env.n = 0: none)
     int n_tris, n_spheres, n_lights, n_tlights;
     // persistent per local pixel
     const uint32_t *pixmap;         // local index -> global pixel index y*W + x

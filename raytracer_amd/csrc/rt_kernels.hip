@@ -918,7 +918,7 @@ template <bool CULL>
 __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane)
 {
     const DevView &v = A.v;
-    const int Ld = v.n_lights, La = v.n_tlights, L = Ld + La;
+    const int Ld = v.n_lights, La = v.n_tlights, Ne = v.env.n, L = Ld + La + Ne;
     const int n_models_prims = v.n_tris + v.n_spheres;       // first light id
     const float E = A.T.tv.extent;
     uint32_t cost = 0, n_shadow = 0, n_bounce = 0;
@@ -983,6 +983,8 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
             const bool on_light = ishit[h] && id >= n_models_prims;
             if (on_light && (bounce == 0 || S[h].from_specular))             // PathTracer.cu:33-47
                 S[h].res = add(S[h].res, mul(S[h].beta, light_L(v.tlights[id - n_models_prims], neg(r.d))));
+            if (!ishit[h] && Ne && (bounce == 0 || S[h].from_specular))      // PathTracer.cu:53-61
+                S[h].res = add(S[h].res, mul(S[h].beta, env_L(v.env, r.d)));
             if (S[h].last) {                                 // traced for its emission only: the break of :64
                 ishit[h] = false;
                 finalize_path(v, p, S[h].res);
@@ -1165,6 +1167,89 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
                     if (lit[h])
                         S[h].le = add(S[h].le, S[h].cur);                             // Scene.cu:120
             }
+            // ---- the environment light: Scene.cu:109-114 -> evaluateDirectLight(.., idx = La, isDelta = false),
+            // EnvironmentLight::lightIllumi (Light.cu:137-155).  H10: lpos = (0, 0, 0).  Its second half
+            // (Scene.cu:253-284) needs no ray: rec.lightidx never equals idx, so l = getLe(r) whatever the ray hits.
+            if (Ne) {
+                v3 so[2], sd[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    cast[h] = false;
+                    so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].cur = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].contrib = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].go_on = false;
+                    if (!lit[h])
+                        continue;
+                    float u[4];
+                    pixel_uniform4(v.pixmap[pixel_of(h)], S[h].draw0 + 1u + (uint32_t)(Ld + La), u);
+                    const Hit &H = S[h].H;
+                    const ModelRec &M = v.models[H.model];
+                    const MatRec &P = v.mats[H.model];
+                    float d0, d1, pdf_light;
+                    env_dist_sample(v.env, u[0], u[1], d0, d1, pdf_light);             // Light.cu:139
+                    const float theta = (float)((double)d1 * kPiD), phi = (float)((double)(2.0f * d0) * kPiD);   // :140
+                    const float sint = m_sinf(theta);                                  // :141
+                    const Ray wi = make_ray(mk3(0.0f, 0.0f, 0.0f),                     // :142 (H10)
+                                            mk3(m_sinf(theta) * m_sinf(phi), m_cosf(theta), m_sinf(theta) * m_cosf(phi)));
+                    v3 color = mk3(0.0f, 0.0f, 0.0f);
+                    if (!(pdf_light < 0.001f) && !(sint < 0.001f)) {                   // :143-147
+                        pdf_light = (float)((double)pdf_light / ((double)(2.0f * sint) * kPiD * kPiD));   // :149
+                        color = env_tex2d(v.env, 0.5f * phi * kEnvInvPi, theta * kEnvInvPi);   // :153
+                    }
+                    const Ray sr = spawn_ray(H, neg(wi.d));                            // Scene.cu:218
+                    const v3 f = scale(brdf_f(H, M, P, S[h].wo, sr.d), fabsf(dot(H.normal, sr.d)));   // :222
+                    cast[h] = !is_black(f);                                            // :224
+                    so[h] = sr.o; sd[h] = sr.d;
+                    S[h].thr = length(sub(sr.o, wi.o)) - 0.01f;                        // :227 rhs, lpos = 0
+                    S[h].go_on = !(pdf_light < 0.001f);                                // :233
+                    if (S[h].go_on && cast[h] && !is_black(color)) {                   // :236
+                        const float pdf_surface = brdf_pdf(H, M, P, S[h].wo, sr.d);    // :244
+                        float weight = pdf_light * pdf_light / (pdf_light * pdf_light + pdf_surface * pdf_surface);
+                        weight /= pdf_light;
+                        S[h].contrib = scale(mul(color, f), weight);                   // :247
+                    }
+                }
+                const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+                if (c0 | c1) {
+                    n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+                    trace(so, sd, cast);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (!lit[h])
+                        continue;
+                    if (cast[h]) {
+                        const float best = h ? w.best.y : w.best.x;
+                        const int32_t sid = h ? w.idy : w.idx;
+                        bool blocked = false;
+                        if (scene_ishit(best) && sid >= 0) {                           // (a triangle light's index never equals idx)
+                            const Ray sr = ray_of(h);
+                            blocked = length(sub(hit_pos(sr, best, sid), sr.o)) < S[h].thr;
+                        }
+                        if (!blocked)
+                            S[h].cur = S[h].contrib;
+                    }
+                    if (S[h].go_on) {                                                  // Scene.cu:253-284
+                        float u[4];
+                        pixel_uniform4(v.pixmap[pixel_of(h)], S[h].draw0 + 1u + (uint32_t)(Ld + La), u);
+                        const Hit &H = S[h].H;
+                        v3 wi = mk3(0.0f, 0.0f, 0.0f);                                 // H9
+                        float pdf_surface = 0.0f;
+                        v3 f = brdf_sample_f(H, v.models[H.model], v.mats[H.model], S[h].wo, wi, pdf_surface, u[2], u[3]);
+                        f = scale(f, fabsf(dot(H.normal, wi)));
+                        const Ray r = spawn_ray(H, wi);
+                        if (!is_black(f) && pdf_surface > 0.001f) {
+                            const float pdf = env_pdf(v.env, wi);                      // :268
+                            if (!(fabsf(pdf) < 0.01f)) {                               // :269
+                                const float weight = pdf_surface * pdf_surface / (pdf_surface * pdf_surface + pdf * pdf);
+                                S[h].cur = add(S[h].cur, divs(scale(mul(env_L(v.env, r.d), f), weight), pdf_surface));   // :280-282
+                            }
+                        }
+                    }
+                    S[h].le = add(S[h].le, S[h].cur);                                  // Scene.cu:120
+                }
+            }
         }
 
         // ---- end of the bounce: PathTracer.cu:73-88
@@ -1200,7 +1285,7 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
                 // :33-52 can read -- off a specular surface, with a light to land on -- then the
                 // break of :64
                 draw[h] += 1u;
-                if (S[h].from_specular && La > 0)
+                if (S[h].from_specular && (La > 0 || Ne))
                     S[h].last = true;
                 else
                     done = true;
@@ -2229,7 +2314,8 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // uniform chunks, three waves per SIMD measured best (C2: +17 % over two).  With bounces
     // the per-bounce state wants the registers: two.  The grid is what is resident at once.
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
-    const int waves = (d0 && v.cull) ? 3 : 2;
+    static const int waves_d0 = [] { const char *e = std::getenv("RT_PATH_WAVES"); return e && std::atoi(e) == 2 ? 2 : 3; }();
+    const int waves = (d0 && v.cull) ? waves_d0 : 2;
     const uint32_t g = grid_for_chunks(n, max_blocks * waves);
     // Cooperative form from which multiple of the mean chunk cost on: a launch with many
     // chunks per resident wave is throughput-bound, and sharing a chunk among four waves
@@ -2248,7 +2334,8 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     }
     if (v.cull) {
         if (!d0) k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else     k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else if (waves == 3) k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else     k_path<true, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     } else {
         if (d0) k_path<false, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else    k_path<false, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);

@@ -242,6 +242,20 @@ struct TriLightRec {
 };
 static_assert(sizeof(TriLightRec) == 128, "TriLightRec must be 128 bytes");
 
+// EnvironmentLight (Light/Light.cuh:105-129) as setUp leaves it (Light.cu:201-234): the image (the
+// texture object's texels) and the Distribution2D tables (PiecewiseConstant.cu:8-22, 65-96), rows
+// back to back.  n = 0: no such light.
+struct EnvView {
+    const float *img;           // [h][w][4]
+    const float *cond_value;    // [h][w]      condition_w[i].value
+    const float *cond_cdf;      // [h][w + 1]  condition_w[i].cdf
+    const float *cond_funint;   // [h]         condition_w[i].funInt
+    const float *marg_value;    // [h]         hmargin->value
+    const float *marg_cdf;      // [h + 1]
+    float marg_funint;
+    int w, h, n;
+};
+
 // Camera after its constructor (Camera/Camera.cu:4-14); pers/raster2world are dead.
 struct CameraRec {
     v3 pos, up, front, right;

@@ -403,7 +403,14 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
             err = "a triangle light's own material must be LAMBERTIAN (Light.cu:115-125)";
             return RT_ERR_UNSUPPORTED;
         }
-    out.general = d->n_tri_lights > 0;
+    if (d->n_env_lights < 0 || d->n_env_lights > 1) {
+        err = "at most one environment light (Scene::getEnvironmentLight reads el[0], Scene.cuh:28-31)";
+        return RT_ERR_UNSUPPORTED;
+    }
+    if (d->n_env_lights == 1 && (!d->env_image || d->env_width < 1 || d->env_height < 1)) {
+        err = "environment light without an image"; return RT_ERR_INVALID;
+    }
+    out.general = d->n_tri_lights > 0 || d->n_env_lights > 0;
     for (int m = 0; m < n_models; m++) {
         const int t = d->model_mat_type[m];
         if (t != kMatLambertian && t != kMatFresnel && t != kMatCook && t != kMatGGX && t != kMatOrenNayar) {
@@ -464,6 +471,41 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
         M = ModelRec{};
         std::memcpy(M.color, d->tl_color + 3 * (size_t)k, 3 * sizeof(float));
         M.mat_type = d->tl_mat_type[k];
+    }
+
+    // EnvironmentLight::setUp (Light.cu:201-234): Distribution2D over the image's luminance
+    // (PiecewiseConstant.cu:65-96), each row and the row integrals a Distribution (:8-22)
+    out.env_n = d->n_env_lights;
+    if (d->n_env_lights == 1) {
+        const int w = d->env_width, h = d->env_height;
+        const float *img = d->env_image;
+        out.env_w = w; out.env_h = h;
+        out.env_img.assign(img, img + 4 * (size_t)w * h);
+        auto make = [](int n, const float *v, float *value, float *cdf) -> float {
+            std::memcpy(value, v, sizeof(float) * (size_t)n);
+            cdf[0] = 0.0f;
+            for (int i = 1; i <= n; i++) cdf[i] = cdf[i - 1] + value[i - 1] / n;
+            const float funInt = cdf[n];
+            for (int i = 1; i <= n; i++) cdf[i] = funInt == 0 ? (float)i / n : cdf[i] / funInt;
+            cdf[n] = 1.0f;
+            return funInt;
+        };
+        out.env_cond_value.assign((size_t)w * h, 0.0f);
+        out.env_cond_cdf.assign((size_t)(w + 1) * h, 0.0f);
+        out.env_cond_funint.assign((size_t)h, 0.0f);
+        out.env_marg_value.assign((size_t)h, 0.0f);
+        out.env_marg_cdf.assign((size_t)h + 1, 0.0f);
+        std::vector<float> ctmp((size_t)w), vtmp((size_t)h);
+        for (int i = 0; i < h; i++) {
+            for (int j = 0; j < w; j++) {
+                const size_t idx = 4 * ((size_t)i * w + j);
+                // rgb2y_xyz (PiecewiseConstant.cu:3-6): the 0.06007 is a double
+                ctmp[j] = (float)((double)(img[idx] + 4.5906f * img[idx + 1]) + 0.06007 * (double)img[idx + 2]);
+            }
+            vtmp[i] = make(w, ctmp.data(), &out.env_cond_value[(size_t)i * w], &out.env_cond_cdf[(size_t)i * (w + 1)]);
+            out.env_cond_funint[i] = vtmp[i];
+        }
+        out.env_marg_funint = make(h, vtmp.data(), out.env_marg_value.data(), out.env_marg_cdf.data());
     }
 
     out.spheres.resize((size_t)d->n_quads);

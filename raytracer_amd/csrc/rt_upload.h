@@ -24,6 +24,10 @@ struct HostScene {
     std::vector<ModelRec> models;
     std::vector<SphereRec> spheres;
     std::vector<LightRec> lights;
+    // EnvironmentLight tables (EnvView): rows back to back
+    int env_w = 0, env_h = 0, env_n = 0;
+    std::vector<float> env_img, env_cond_value, env_cond_cdf, env_cond_funint, env_marg_value, env_marg_cdf;
+    float env_marg_funint = 0.0f;
     std::vector<MatRec> mats;            // one per ModelRec
     bool general = false;                // non-Lambertian materials or triangle lights
     std::vector<TriLightRec> tlights;    // triangle lights (their Materials: models[n_models + k])

@@ -92,7 +92,9 @@ class SceneDesc(C.Structure):
                 ("quad_type", _IP), ("n_point_lights", C.c_int32), ("pl_pos", _FP),
                 ("pl_illum", _FP), ("n_dir_lights", C.c_int32), ("dl_dir", _FP), ("dl_illum", _FP),
                 ("n_tri_lights", C.c_int32), ("tl_pos", _FP), ("tl_illum", _FP), ("tl_two_side", _IP),
-                ("tl_mat_type", _IP), ("tl_color", _FP), ("model_param", _FP)]
+                ("tl_mat_type", _IP), ("tl_color", _FP), ("model_param", _FP),
+                ("n_env_lights", C.c_int32), ("env_width", C.c_int32), ("env_height", C.c_int32),
+                ("env_image", _FP)]
 
 
 @dataclass
@@ -121,6 +123,8 @@ class SceneData:
     tl_two_side: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
     tl_mat_type: np.ndarray = field(default_factory=lambda: np.zeros((0,), np.int32))
     tl_color: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    # EnvironmentLight(texture, w, h) (Light.cuh:108): [h, w, 4] floats as stbi_loadf(.., 4) returns them; None = no such light
+    env_image: np.ndarray = None
 
     @property
     def n_tris(self):
@@ -146,7 +150,7 @@ class SceneData:
     def n_lights(self):
         """Lights in Scene::sampleAllLight order (Scene.cu:83-114): point, directional, triangle."""
         return int(self.pl_pos.shape[0]) + int(np.asarray(self.dl_dir).reshape(-1, 3).shape[0]) + \
-            self.n_tri_lights
+            self.n_tri_lights + (0 if self.env_image is None else 1)
 
     @property
     def n_tri_lights(self):
@@ -178,6 +182,9 @@ class SceneData:
         self.tl_two_side = _i32(self.tl_two_side, (nl,))
         self.tl_mat_type = _i32(self.tl_mat_type, (nl,))
         self.tl_color = _f32(self.tl_color, (nl, 3))
+        if self.env_image is not None:
+            self.env_image = np.ascontiguousarray(self.env_image, np.float32)
+            assert self.env_image.ndim == 3 and self.env_image.shape[2] == 4
         assert self.pl_pos.shape == self.pl_illum.shape
         assert self.dl_dir.shape == self.dl_illum.shape
         assert self.quad_type.shape[0] == self.quad_coeff.shape[0]
@@ -205,6 +212,10 @@ class SceneData:
         d.n_tri_lights = self.n_tri_lights
         d.tl_pos, d.tl_illum, d.tl_color = fp(self.tl_pos), fp(self.tl_illum), fp(self.tl_color)
         d.tl_two_side, d.tl_mat_type = ip(self.tl_two_side), ip(self.tl_mat_type)
+        if self.env_image is not None:
+            d.n_env_lights = 1
+            d.env_height, d.env_width = int(self.env_image.shape[0]), int(self.env_image.shape[1])
+            d.env_image = fp(self.env_image)
         return d
 
 

@@ -341,6 +341,31 @@ def demo_scene():
     return b.build()
 
 
+def synthetic_environment(width=48, height=24, seed=11):
+    """A small seeded stand-in for the reference's environment.png as stbi_loadf(.., 4) would hand
+    it over ([h, w, 4] floats): a vertical sky gradient, horizontal colour bands, noise, and a
+    bright 'sun' patch so that the Distribution2D is far from uniform."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    img = np.zeros((height, width, 4), np.float32)
+    img[..., 0] = 0.15 + 0.6 * (1.0 - yy / height)
+    img[..., 1] = 0.2 + 0.5 * np.sin(xx / width * 2 * np.pi) ** 2
+    img[..., 2] = 0.35 + 0.4 * (yy / height)
+    img[..., :3] += rng.uniform(0.0, 0.05, (height, width, 3)).astype(np.float32)
+    img[height // 6: height // 6 + 2, (2 * width) // 3: (2 * width) // 3 + 3, :3] = (24.0, 20.0, 14.0)
+    img[..., 3] = 1.0
+    return img
+
+
+def demo_scene_with_environment():
+    """The reference's demo scene as it is (kernel.cu:268-313): two spheres, one two-sided
+    TriangleLight and one EnvironmentLight, light_size = {0, 0, 1, 1} -- with a synthetic image in
+    place of environment.png."""
+    scene = demo_scene()
+    scene.env_image = synthetic_environment()
+    return scene.normalise()
+
+
 def area_test_scene(seed=7):
     """mixed_test_scene lit by every supported light type at once: two point lights, one
     directional light, a one-sided triangle light above the scene (facing down) and a two-sided

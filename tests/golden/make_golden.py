@@ -43,6 +43,10 @@ CASES = {
     "area": (("area", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 5)]),
     # every BRDF of material.cu, one model each
     "materials": (("materials", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (3, 6)]),
+    # the reference's demo scene with its environment light (a synthetic image) and the materials
+    # scene under one: EnvironmentLight + Distribution2D
+    "demo_env": (("demo_env", {}), 160, 120, (40, 20, 120, 100), [(2, 0), (3, 6)]),
+    "materials_env": (("materials_env", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 6)]),
 }
 
 
@@ -50,7 +54,7 @@ SCENE_FIELDS = ["tri_pos", "tri_nrm", "tri_model", "mesh_first", "mesh_count", "
                 "model_mat_type", "model_color", "quad_coeff", "quad_type", "pl_pos", "pl_illum"]
 OPTIONAL_SCENE_FIELDS = ["dl_dir", "dl_illum",        # absent from fixtures written before them
                          "tl_pos", "tl_illum", "tl_two_side", "tl_mat_type", "tl_color",
-                         "model_param"]
+                         "model_param", "env_image"]
 
 
 def load_case(name):
@@ -78,8 +82,12 @@ def build_case(name):
         scene, _ = {"mixed": scenes.mixed_test_scene, "sun": scenes.sun_test_scene,
                     "area": scenes.area_test_scene, "materials": scenes.material_test_scene}[kind]()
         cam = CameraArgs.for_image(w, h, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
-    elif kind == "demo":
-        scene = scenes.demo_scene()
+    elif kind == "materials_env":
+        scene, _ = scenes.material_test_scene()
+        scene.env_image = scenes.synthetic_environment(32, 16, seed=5)
+        cam = CameraArgs.for_image(w, h, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    elif kind in ("demo", "demo_env"):
+        scene = scenes.demo_scene() if kind == "demo" else scenes.demo_scene_with_environment()
         cam = CameraArgs.for_image(w, h)
     else:
         cfg = scenes.CONFIGS[kind](w, h, **kw)
@@ -103,7 +111,8 @@ def main():
             out[k + "_t"] = r["t"]
             out[k + "_rays"] = np.array([r["primary"], r["shadow"], r["bounce"]], np.int64)
         for f in SCENE_FIELDS + OPTIONAL_SCENE_FIELDS:
-            out["scene_" + f] = getattr(scene, f)
+            if getattr(scene, f) is not None:
+                out["scene_" + f] = getattr(scene, f)
         out["scene_n_tri_models"] = np.array(scene.n_tri_models)
         out["camera"] = np.array(json.dumps(dict(pos=cam.pos, lookat=cam.lookat, fov=cam.fov,
                                                  near=cam.near, far=cam.far, res=cam.res,

@@ -245,3 +245,42 @@ def test_rough2alpha_and_specular_emission():
     # so head-on rays almost always reflect; the few that refract carry the light's emission)
     assert glass > 0.05
     assert matte == 0.0           # the Lambertian front face cannot see the light behind it
+
+
+def test_environment_light_emission_and_sampling():
+    """EnvironmentLight (Light.cu:137-234): with nothing to hit every camera ray returns getLe -- a
+    constant image comes back as that constant whatever the direction (the filter's weights sum to
+    one), a two-band image puts each band where L's (phi, theta) -> (u, v) mapping says: v = theta /
+    pi, theta measured from +y, so the top rows of the image are straight up.  A Lambertian floor
+    under a bright top half is lit through the Distribution2D + MIS branch (Scene.cu:242-284)."""
+    from raytracer_amd.scene import SceneBuilder, identity
+    cam = CameraArgs.for_image(32, 24)
+    img = np.zeros((8, 16, 4), np.float32)
+    img[..., :3] = (0.25, 0.5, 0.75)
+    img[..., 3] = 1.0
+    s = SceneBuilder().build()
+    s.env_image = img
+    r = orc.render(s, cam, 32, 24, spp=2, max_depth=0)
+    assert np.all(r["prim_id"] == -1)
+    np.testing.assert_allclose(r["rgba"][..., :3], np.broadcast_to(np.float32((0.25, 0.5, 0.75)), (24, 32, 3)), rtol=1e-6)
+    img2 = img.copy()
+    img2[:4, :, :3] = (9.0, 9.0, 9.0)                        # theta < pi/2: the upper hemisphere
+    img2[4:, :, :3] = (0.0, 0.0, 0.0)
+    s.env_image = img2
+    r = orc.render(s, cam, 32, 24, spp=1, max_depth=0)
+    up, down = r["rgba"][20:, :, 0].mean(), r["rgba"][:4, :, 0].mean()      # row 0 is the bottom of the image
+    assert up > 8.0 and down < 1.0
+    b = SceneBuilder()
+    b.add_triangle([(-12.0, -3.0, 2.0), (12.0, -3.0, 2.0), (0.0, -3.0, -30.0)], [(0.0, 1.0, 0.0)] * 3, identity(),
+                   (0.7, 0.7, 0.7))
+    s = b.build()
+    cam2 = CameraArgs.for_image(32, 24, pos=(0.0, 2.0, 0.0), lookat=(0.0, -1.0, -6.0))
+    def floor_mean(image):
+        s.env_image = image
+        rr = orc.render(s, cam2, 32, 24, spp=16, max_depth=0, crop=(8, 0, 24, 8))
+        assert np.all(rr["prim_id"] == 0)
+        return float(rr["rgba"][..., 0].mean())
+    lit, unlit = floor_mean(img2), floor_mean(np.ascontiguousarray(img2[::-1]))      # bright half above / below the floor
+    # (not black below: Distribution::sample returns offset + fraction, PiecewiseConstant.cu:39, so the sampled
+    # theta = sample.y * pi wraps around the sphere many times, Light.cu:140)
+    assert lit > 0.5 and lit > 3.0 * unlit

@@ -8,7 +8,7 @@ shift
 mkdir -p $O
 for rep in 1 2; do
   for knobs in "$@"; do
-    tag=$(echo "$knobs" | tr ',=' '__')
+    tag=$(echo "$knobs" | tr ',=/' '___')
     env $(echo "$knobs" | tr ',' ' ') timeout -k 10 300 python bench.py --config $CFG --no-cpu "${ARGS[@]}" > $O/${CFG}_${tag}_$rep.json 2> $O/${CFG}_${tag}_$rep.err || echo "FAILED $knobs"
     python3 - "$O/${CFG}_${tag}_$rep.json" "$knobs" <<'PY'
 import json,sys

@@ -388,7 +388,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                 if (COOP) merge_in();
                 RT_MARK(sp, 7);
                 const NodeGroup *gp = &tv.groups[lane_get(lvloff, l) + g];
-                uint32_t key[4], n_pass = 0, lb = 0;
+                uint32_t key[4], n_pass = 0, lb = 0, tmask = 0;
                 // One child: `test` fills the two rays' verdicts and entry parameters and says
                 // whether the box is dead (lo = +inf, hi = -inf: padding, or a triangle
                 // Model.cu:99 always rejects -- dead for every ray, including the unculled ones).
@@ -401,7 +401,11 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                         uint32_t node = g * kTreeArity + (uint32_t)j;
                         take = ((node * 2654435761u) >> 30) == wib;
                     }
-                    if (take) {
+                    if (!ORDER) {
+                        // occlusion rays visit in index order: the state word is just the mask of
+                        // the children to visit
+                        tmask |= (uint32_t)take << j;
+                    } else if (take) {
                         // visit order: entry parameter of the first passing lane (a coherent
                         // wave's rays agree on it closely enough; the smaller of the lane's
                         // passing rays, compared as integers: entry parameters are >= +0); the
@@ -451,16 +455,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                 }
                 uint32_t word;
                 if (!ORDER) {
-                    // index order: the taken children, compacted (no sorting network: 12 scalar
-                    // instructions fewer per group)
-                    uint32_t w2 = 0, sh = 0;
-#pragma unroll
-                    for (int j = 0; j < kTreeArity; j++) {
-                        const uint32_t tk = key[j] == (uint32_t)j ? 1u : 0u;
-                        w2 |= ((uint32_t)j & (0u - tk)) << sh;
-                        sh += 2u * tk;
-                    }
-                    word = w2 | n_pass << 8;
+                    word = tmask;
                 } else {
                     cswap(key[0], key[1]); cswap(key[2], key[3]);
                     cswap(key[0], key[2]); cswap(key[1], key[3]);
@@ -472,16 +467,24 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                     lanebits = lb;
                 expand = false;
             }
+            // ORDER: bits 0-7 the children still to visit, nearest first, 2 bits each, bits 8-10 how
+            // many; else: bit j = child j still to visit
             uint32_t word = lane_get(state, l);
-            if ((word >> 8) == 0) {
+            if ((ORDER ? word >> 8 : word) == 0) {
                 if (l == tv.top)
                     break;
                 l++;
                 g >>= 2;
                 continue;
             }
-            int j = (int)(word & 3u);
-            state = lane_set(state, l, ((word & 0xffu) >> 2) | ((word >> 8) - 1u) << 8);
+            int j;
+            if (ORDER) {
+                j = (int)(word & 3u);
+                state = lane_set(state, l, ((word & 0xffu) >> 2) | ((word >> 8) - 1u) << 8);
+            } else {
+                j = __builtin_ctz(word);
+                state = lane_set(state, l, word & (word - 1u));
+            }
             uint32_t node = g * kTreeArity + (uint32_t)j;
             if (l == 0) {
                 cost++;

@@ -859,3 +859,36 @@ def test_environment_light_limits(gpu_ctx_factory):
     d.n_env_lights = 1
     d.env_image = C.POINTER(C.c_float)()
     assert abi.lib().rt_upload_scene(ctx._h, C.byref(d)) == abi.RT_ERR_INVALID
+
+
+@pytest.mark.parametrize("size", [(8, 8), (40, 24), (130, 70)])
+def test_batch_kernel_equals_path_kernel_on_odd_shapes(gpu_ctx_factory, monkeypatch, size):
+    """k_batch against the per-sample path kernel (RT_BATCH_MIN_TOP keeps a context off k_batch) on
+    images and partitions that leave units ragged or lanes without a pixel: tiny frames, 1 / 3 / 8
+    ranks, sample counts that end a batch early -- every bit of the three buffers, and the RNG state
+    (a second call continues identically)."""
+    w, h = size
+    cfg = scenes.c3(w, h, f=10, ground=(8, 5))
+    monkeypatch.setenv("RT_BATCH_MIN_TOP", "99")
+    plain = gpu_ctx_factory(w, h)
+    monkeypatch.delenv("RT_BATCH_MIN_TOP")
+    fast = gpu_ctx_factory(w, h)
+    for ctx in (plain, fast):
+        ctx.upload_scene(cfg.scene)
+        ctx.set_camera(cfg.camera)
+    for world in (1, 3, 8):
+        for rank in sorted({0, world - 1}):
+            for ctx in (plain, fast):
+                ctx.set_partition(rank, world, 8)
+                ctx.reset_stats()
+            for spp in (1, 5, 70):
+                out = []
+                for ctx in (plain, fast):
+                    ctx.render(spp, 0)
+                    out.append(ctx.read_framebuffer())
+                assert np.array_equal(out[0]["rgba"].view(np.uint32), out[1]["rgba"].view(np.uint32)), (world, rank, spp)
+                assert np.array_equal(out[0]["prim_id"], out[1]["prim_id"])
+                assert np.array_equal(out[0]["t"].view(np.uint32), out[1]["t"].view(np.uint32))
+            sp, sf = plain.stats(), fast.stats()
+            assert sp.batch_launches == 0 and (sf.batch_launches > 0 or fast.local_pixel_count() == 0)
+            assert (sp.primary_rays, sp.shadow_rays) == (sf.primary_rays, sf.shadow_rays)

@@ -892,3 +892,34 @@ def test_batch_kernel_equals_path_kernel_on_odd_shapes(gpu_ctx_factory, monkeypa
             sp, sf = plain.stats(), fast.stats()
             assert sp.batch_launches == 0 and (sf.batch_launches > 0 or fast.local_pixel_count() == 0)
             assert (sp.primary_rays, sp.shadow_rays) == (sf.primary_rays, sf.shadow_rays)
+
+
+def test_general_kernel_partition_union(gpu_ctx_factory):
+    """The general kernel under the tile partition: three ranks' images of the every-BRDF scene under
+    an environment light add up to the single-context image bit for bit (RNG streams are keyed by the
+    global pixel index), and scene_hit still answers on a partitioned context."""
+    scene, _ = scenes.material_test_scene()
+    scene.env_image = scenes.synthetic_environment(32, 16, seed=5)
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    whole = gpu_ctx_factory(96, 64)
+    whole.upload_scene(scene)
+    whole.set_camera(cam)
+    whole.render(3, 4)
+    ref = whole.read_framebuffer()
+    acc = np.zeros_like(ref["rgba"])
+    seen = np.zeros(ref["prim_id"].shape, bool)
+    part = gpu_ctx_factory(96, 64)
+    part.upload_scene(scene)
+    part.set_camera(cam)
+    for rank in range(3):
+        part.set_partition(rank, 3, 8)
+        part.render(2, 4)
+        part.render(1, 4)
+        got = part.read_framebuffer()
+        mine = got["prim_id"] != -2
+        assert not (seen & mine).any()
+        seen |= mine
+        acc[mine] = got["rgba"][mine]
+        assert np.array_equal(got["prim_id"][mine], ref["prim_id"][mine])
+    assert seen.all()
+    assert np.array_equal(acc.view(np.uint32), ref["rgba"].view(np.uint32))

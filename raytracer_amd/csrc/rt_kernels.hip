@@ -745,7 +745,12 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         S[1].save(st + State::kSlots * kBlock);
         asm volatile("" ::: "memory");
         Stamps sp0;
-        traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
+        // (two copies of the traversal: shadow rays of the occlusion form visit children in index
+        // order and keep them as a mask -- cheaper bookkeeping per node group; C2 +1.9 %)
+        if (j >= 0 && A.occlusion)
+            traverse<CULL, COOP, false>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
+        else
+            traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
         asm volatile("" ::: "memory");
         S[0].load(st);
         S[1].load(st + State::kSlots * kBlock);

@@ -2356,8 +2356,7 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // uniform chunks, three waves per SIMD measured best (C2: +17 % over two).  With bounces
     // the per-bounce state wants the registers: two.  The grid is what is resident at once.
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
-    static const int waves_d0 = [] { const char *e = std::getenv("RT_PATH_WAVES"); return e && std::atoi(e) == 2 ? 2 : 3; }();
-    const int waves = (d0 && v.cull) ? waves_d0 : 2;
+    const int waves = (d0 && v.cull) ? 3 : 2;
     const uint32_t g = grid_for_chunks(n, max_blocks * waves);
     // Cooperative form from which multiple of the mean chunk cost on: a launch with many
     // chunks per resident wave is throughput-bound, and sharing a chunk among four waves
@@ -2376,8 +2375,7 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     }
     if (v.cull) {
         if (!d0) k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else if (waves == 3) k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else     k_path<true, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else     k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     } else {
         if (d0) k_path<false, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else    k_path<false, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);

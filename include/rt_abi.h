@@ -45,7 +45,8 @@ typedef struct rt_context rt_context;
  * (hit-able area lights: Scene.cu:43-64, emission core/PathTracer.cu:33-52, the MIS branch
  * Scene.cu:242-284) are supported; a scene with triangle lights renders through the general
  * path kernel, not the depth-0 batch kernel; so does one with an environment light
- * (Light.cu:137-234, PiecewiseConstant.cu; at most one, as Scene::getEnvironmentLight reads).
+ * (Light.cu:137-234, PiecewiseConstant.cu; at most one, as Scene::getEnvironmentLight reads), and
+ * one with mesh textures (Model.cu:60-88,304-309, Texture/Texture.cu; software tex2DGrad, DESIGN H13).
  * A light hit reports prim_id = n_tris + n_quads + its index. */
 typedef struct rt_scene_desc {
     int32_t n_tri_models;          /* model_size[0]                               */
@@ -84,6 +85,14 @@ typedef struct rt_scene_desc {
     int32_t env_width, env_height;
     const float *env_image;        /* [env_height][env_width][4] floats, as stbi_loadf(.., 4) hands them to
                                       EnvironmentLight(texture, w, h) (kernel.cu:271-272, Light.cuh:108) */
+    const float *tri_uv;           /* [n_tris][3][2] Triangle::vText (Model.cuh:75), what Mesh::readFile takes
+                                      from the OBJ's vt lines (Model.cu:227-229); NULL = zeros */
+    int32_t n_textures;            /* images bound with Mesh::initTexture(data, w, h) (Model.cu:315-319) */
+    const int32_t *mesh_texture;   /* [n_meshes] index of the image Mesh j bound, -1 = none: its hits keep the
+                                      BRDF's own colour (hazard H5) */
+    const int32_t *tex_size;       /* [n_textures][2] width, height */
+    const float *tex_data;         /* the images back to back, each [height][width][4] floats; the library
+                                      builds the mip chain of Texture.cu:48-133 at upload */
 } rt_scene_desc;
 
 /* Camera(pos, lookat, fov, near, far, int2 res, up)          (Camera/Camera.cuh:11).

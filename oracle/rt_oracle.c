@@ -399,23 +399,26 @@ static int tl_hit(const orc_scene *s, int k, const ray_t *r, rec_t *rec)
 }
 
 /* ---------------------------------------------------------------- Scene::hit */
+static f3 mesh_texture_color(const orc_scene *s, int mesh, int g, const rec_t *rec);
 /* Scene/Scene.cu:8-67 with Mesh::hit (Model/Model.cu:287-313) inlined. */
 static int scene_hit(const orc_scene *s, const ray_t *r, rec_t *rec)
 {
     for (int j = 0; j < s->n_tri_models; j++)                       /* :17-23 */
         tri_hit(s, j, r, rec);
     for (int j = 0; j < s->n_meshes; j++) {                         /* :24-30 */
-        int ishit = 0;
+        int ishit = 0, idx = -1;
         int first = s->mesh_first[j], number = s->mesh_count[j];
         for (int i = 0; i < number; i++)                            /* Model.cu:291-298 */
-            if (tri_hit(s, first + i, r, rec))
+            if (tri_hit(s, first + i, r, rec)) {
                 ishit = 1;
+                idx = first + i;
+            }
         if (ishit) {                                                /* Model.cu:301-310 */
             int model = s->n_tri_models + j;
             rec->material = model;
             rec->material_type = s->model_mat_type[model];
-            /* H5: Mesh::Texture is never bound; the lookup yields (-1,-1,-1). */
-            rec->color = mk3(-1.0f, -1.0f, -1.0f);
+            /* :304-309.  H5: a mesh whose Texture was never bound yields (-1,-1,-1). */
+            rec->color = mesh_texture_color(s, j, idx, rec);
         }
     }
     for (int j = 0; j < s->n_quads; j++)                            /* :31-37 */
@@ -1224,6 +1227,238 @@ static ray_t cam_generate_ray(const cam_t *c, float x, float y)
     return mk_ray(c->pos, normalize3(dir));
 }
 
+/* Camera/Camera.cu:26-42 getxy (only the texture LOD reads it) */
+static f2 cam_getxy(const cam_t *c, f3 poso)
+{
+    const float step = 0.25f;
+    f3 dir = normalize3(sub3(poso, c->pos));
+    f2 res = { 0.0f, 0.0f };
+    if (dot3(dir, c->front) == 0.0f)
+        return res;
+    float aspect = (float)c->res_x / c->res_y;
+    float t = c->n / dot3(dir, c->front);
+    f3 rpos = scale3(dir, t);
+    res.x = dot3(rpos, c->right) * c->res_x / step / aspect;
+    res.y = dot3(rpos, c->up) * c->res_y / step;
+    return res;
+}
+
+/* ---------------------------------------------------------------- mesh textures */
+/* Texture/Texture.cu:135-186 initImages: a float4 mip-mapped array (levels = getMipMapLevels, :2-13),
+ * level 0 = the caller's image, the others by generateMipMaps (:48-133), and a texture object with
+ * normalised coordinates, clamp addressing, linear filtering within and between levels (:174-182).
+ * H13: the filtering is the texture unit's and is not bit-specified; it is restated from the CUDA
+ * programming guide's texture-fetching appendix as H11 does for tex2D -- xB = x N - 0.5, i = floor(xB),
+ * alpha = frac(xB) in 8 fractional bits (rounded to nearest), texel indices clamped to the edge -- and
+ * tex2DGrad's level from the OpenGL rule: rho = max(|dPdx scaled to texels|, |dPdy scaled to texels|)
+ * over level 0's size, lambda = log2(rho) (float rounding of the double function) clamped to
+ * [0, levels - 1] and kept in 8 fractional bits, the two nearest levels blended linearly. */
+typedef struct { int w, h, levels; float **lvl; int *lw, *lh; } tex_t;
+int orc_texture_levels(int w, int h)
+{
+    size_t sz = (size_t)(w > h ? w : h);                            /* Texture.cu:3 (depth 0) */
+    int levels = 0;
+    while (sz) {
+        sz /= 2;
+        levels++;
+    }
+    return levels;
+}
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static void tex_fetch(const float *img, int w, int h, float x, float y, float out[4])
+{
+    float xb = x * (float)w - 0.5f, yb = y * (float)h - 0.5f;
+    if (!(xb > -1.0f)) xb = -1.0f;                                  /* clamp addressing (and NaN) */
+    if (xb > (float)w) xb = (float)w;
+    if (!(yb > -1.0f)) yb = -1.0f;
+    if (yb > (float)h) yb = (float)h;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = floorf((xb - fi) * 256.0f + 0.5f) / 256.0f, b = floorf((yb - fj) * 256.0f + 0.5f) / 256.0f;
+    int i0 = (int)fi, j0 = (int)fj;
+    int i[2] = { clampi(i0, 0, w - 1), clampi(i0 + 1, 0, w - 1) };
+    int j[2] = { clampi(j0, 0, h - 1), clampi(j0 + 1, 0, h - 1) };
+    for (int c = 0; c < 4; c++) {
+        float t00 = img[4 * ((size_t)j[0] * w + i[0]) + c], t10 = img[4 * ((size_t)j[0] * w + i[1]) + c];
+        float t01 = img[4 * ((size_t)j[1] * w + i[0]) + c], t11 = img[4 * ((size_t)j[1] * w + i[1]) + c];
+        out[c] = (1 - a) * (1 - b) * t00 + a * (1 - b) * t10 + (1 - a) * b * t01 + a * b * t11;
+    }
+}
+/* Texture.cu:14-45 d_mipmap over one level (:48-133 generateMipMaps): four bilinear taps of the
+ * level above at the corners of the texel, averaged and clamped to 1 */
+static void tex_downsample(const float *src, int sw, int sh, float *dst, int dw, int dh)
+{
+    float px = (float)(1.0 / (double)(float)dw);                    /* :19 */
+    float py = (float)(1.0 / (double)(float)dh);                    /* :20 */
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            float a[4], b[4], c[4], d[4];
+            tex_fetch(src, sw, sh, (float)(x + 0) * px, (float)(y + 0) * py, a);   /* :30-33 */
+            tex_fetch(src, sw, sh, (float)(x + 1) * px, (float)(y + 0) * py, b);
+            tex_fetch(src, sw, sh, (float)(x + 1) * px, (float)(y + 1) * py, c);
+            tex_fetch(src, sw, sh, (float)(x + 0) * px, (float)(y + 1) * py, d);
+            for (int k = 0; k < 4; k++) {
+                float col = a[k] + b[k] + c[k] + d[k];
+                col /= 4.0f;                                        /* :36 */
+                dst[4 * ((size_t)y * dw + x) + k] = fminf(col, 1.0f);   /* :37 */
+            }
+        }
+}
+static void tex_make(tex_t *t, const float *img, int w, int h)
+{
+    t->w = w; t->h = h;
+    t->levels = orc_texture_levels(w, h);                           /* Texture.cu:145 */
+    t->lvl = (float **)malloc(sizeof(float *) * (size_t)t->levels);
+    t->lw = (int *)malloc(sizeof(int) * (size_t)t->levels);
+    t->lh = (int *)malloc(sizeof(int) * (size_t)t->levels);
+    t->lvl[0] = (float *)malloc(sizeof(float) * 4 * (size_t)w * h);
+    memcpy(t->lvl[0], img, sizeof(float) * 4 * (size_t)w * h);      /* :150-159 */
+    t->lw[0] = w; t->lh[0] = h;
+    for (int l = 1; l < t->levels; l++) {                           /* :54-58 */
+        t->lw[l] = t->lw[l - 1] / 2 > 1 ? t->lw[l - 1] / 2 : 1;
+        t->lh[l] = t->lh[l - 1] / 2 > 1 ? t->lh[l - 1] / 2 : 1;
+        t->lvl[l] = (float *)malloc(sizeof(float) * 4 * (size_t)t->lw[l] * t->lh[l]);
+        tex_downsample(t->lvl[l - 1], t->lw[l - 1], t->lh[l - 1], t->lvl[l], t->lw[l], t->lh[l]);
+    }
+}
+static void tex_drop(tex_t *t)
+{
+    for (int l = 0; l < t->levels; l++) free(t->lvl[l]);
+    free(t->lvl); free(t->lw); free(t->lh);
+}
+/* tex2DGrad<float4>(Texture, x, y, dPdx, dPdy) (Model.cu:309), H13 */
+static f3 tex_grad(const tex_t *t, float x, float y, f2 dpdx, f2 dpdy)
+{
+    float ax = dpdx.x * (float)t->w, ay = dpdx.y * (float)t->h;
+    float bx = dpdy.x * (float)t->w, by = dpdy.y * (float)t->h;
+    float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+    float lam = 0.0f;
+    if (rho > 1.0f)
+        lam = fminf((float)log2((double)rho), (float)(t->levels - 1));
+    float lq = floorf(lam * 256.0f + 0.5f) / 256.0f;
+    int d = (int)floorf(lq);
+    float wgt = lq - (float)d;
+    if (d >= t->levels - 1) {
+        d = t->levels - 1;
+        wgt = 0.0f;
+    }
+    float c0[4], c1[4];
+    tex_fetch(t->lvl[d], t->lw[d], t->lh[d], x, y, c0);
+    if (wgt == 0.0f)
+        return mk3(c0[0], c0[1], c0[2]);
+    tex_fetch(t->lvl[d + 1], t->lw[d + 1], t->lh[d + 1], x, y, c1);
+    return mk3((1 - wgt) * c0[0] + wgt * c1[0], (1 - wgt) * c0[1] + wgt * c1[1], (1 - wgt) * c0[2] + wgt * c1[2]);
+}
+int orc_texture_mip(const float *img, int w, int h, int level, float *out, int *lw, int *lh)
+{
+    if (!img || w < 1 || h < 1 || level < 0 || level >= orc_texture_levels(w, h))
+        return -1;
+    tex_t t;
+    tex_make(&t, img, w, h);
+    if (out) memcpy(out, t.lvl[level], sizeof(float) * 4 * (size_t)t.lw[level] * t.lh[level]);
+    if (lw) *lw = t.lw[level];
+    if (lh) *lh = t.lh[level];
+    tex_drop(&t);
+    return 0;
+}
+int orc_tex2d_grad(const float *img, int w, int h, float u, float v, const float dpdx[2],
+                   const float dpdy[2], float rgb[3])
+{
+    if (!img || w < 1 || h < 1)
+        return -1;
+    tex_t t;
+    tex_make(&t, img, w, h);
+    f2 dx = { dpdx[0], dpdx[1] }, dy = { dpdy[0], dpdy[1] };
+    f3 c = tex_grad(&t, u, v, dx, dy);
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+    tex_drop(&t);
+    return 0;
+}
+
+/* The texture objects Mesh::initTexture makes once on the host and the camera pathTracer hands every
+ * record (PathTracer.cu:30, Scene.cu:223): set at the entry of every API call that renders and dropped
+ * at its end, like the environment tables (test infrastructure: one call at a time).  No camera
+ * (orc_trace_ray): getdxdy returns zeros (IntersectionRecord.cuh:62-63). */
+static tex_t *g_tex_cur = NULL;
+static int g_tex_n = 0;
+static const cam_t *g_cam_cur = NULL;
+static void tex_begin(const orc_scene *s, const cam_t *cam)
+{
+    g_cam_cur = cam;
+    g_tex_n = 0;
+    g_tex_cur = NULL;
+    if (s->n_textures > 0 && s->tex_size && s->tex_data && s->mesh_texture) {
+        g_tex_cur = (tex_t *)malloc(sizeof(tex_t) * (size_t)s->n_textures);
+        const float *img = s->tex_data;
+        for (int k = 0; k < s->n_textures; k++) {
+            int w = s->tex_size[2 * k], h = s->tex_size[2 * k + 1];
+            tex_make(&g_tex_cur[k], img, w, h);
+            img += 4 * (size_t)w * h;
+        }
+        g_tex_n = s->n_textures;
+    }
+}
+static void tex_end(void)
+{
+    for (int k = 0; k < g_tex_n; k++) tex_drop(&g_tex_cur[k]);
+    free(g_tex_cur);
+    g_tex_cur = NULL;
+    g_tex_n = 0;
+    g_cam_cur = NULL;
+}
+/* Model.cu:304-309 for triangle g (traversal index) of mesh `mesh`, the last one that updated rec:
+ * Triangle::anyPoint (:60-88), IntersectRecord::getdxdy (IntersectionRecord.cuh:60-80), tex2DGrad. */
+static f3 mesh_texture_color(const orc_scene *s, int mesh, int g, const rec_t *rec)
+{
+    if (!g_tex_cur || s->mesh_texture[mesh] < 0 || s->mesh_texture[mesh] >= g_tex_n)
+        return mk3(-1.0f, -1.0f, -1.0f);                            /* H5 */
+    const tex_t *tex = &g_tex_cur[s->mesh_texture[mesh]];
+    const float *pp = s->tri_pos + 9 * (size_t)g;
+    m4 M = load_m4(s->model_xf + 16 * (size_t)s->tri_model[g]);
+    f3 pos[3] = { mk3(pp[0], pp[1], pp[2]), mk3(pp[3], pp[4], pp[5]), mk3(pp[6], pp[7], pp[8]) };
+    f2 vt[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
+    if (s->tri_uv)
+        for (int i = 0; i < 3; i++) {
+            vt[i].x = s->tri_uv[6 * (size_t)g + 2 * i];
+            vt[i].y = s->tri_uv[6 * (size_t)g + 2 * i + 1];
+        }
+    f3 Pos = rec->pos;
+    /* anyPoint, Model.cu:61-87 */
+    f3 ta = m4_apply3(&M, pos[0]), tb = m4_apply3(&M, pos[1]), tc = m4_apply3(&M, pos[2]);
+    float S = 2.0f * tri_area(&M, pos);
+    float s2 = length3(cross3(sub3(Pos, tc), sub3(Pos, ta)));
+    float s3 = length3(cross3(sub3(Pos, tc), sub3(Pos, tb)));
+    float m1 = s3 / S, m2 = s2 / S, m3 = 1.0f - m1 - m2;
+    f2 UV = { vt[0].x * m1 + vt[1].x * m2 + vt[2].x * m3, vt[0].y * m1 + vt[1].y * m2 + vt[2].y * m3 };   /* :68 = rec.uv (:117,132) */
+    if (m3 > m2) {                                                  /* :69-84: 0.01, 0.02 are doubles */
+        if (m3 > m1) {
+            m1 = (float)((double)m1 + 0.01); m2 = (float)((double)m2 + 0.01); m3 = (float)((double)m3 - 0.02);
+        } else {
+            m2 = (float)((double)m2 + 0.01); m3 = (float)((double)m3 + 0.01); m1 = (float)((double)m1 - 0.02);
+        }
+    } else {
+        if (m1 > m2) {
+            m2 = (float)((double)m2 + 0.01); m3 = (float)((double)m3 + 0.01); m1 = (float)((double)m1 - 0.02);
+        } else {
+            m1 = (float)((double)m1 + 0.01); m3 = (float)((double)m3 + 0.01); m2 = (float)((double)m2 - 0.02);
+        }
+    }
+    f2 anyUV = { vt[0].x * m1 + vt[1].x * m2 + vt[2].x * m3, vt[0].y * m1 + vt[1].y * m2 + vt[2].y * m3 };   /* :86 */
+    f3 anyPos = add3(scale3(sub3(Pos, ta), m1), scale3(sub3(Pos, tb), m2));                                   /* :87 */
+    /* getdxdy(rec.pos, UV, anyPos, anyUV) */
+    f2 dx = { 0.0f, 0.0f }, dy = { 0.0f, 0.0f };
+    if (g_cam_cur) {
+        f2 duv = { anyUV.x - UV.x, anyUV.y - UV.y };
+        f2 xy1 = cam_getxy(g_cam_cur, Pos), xy2 = cam_getxy(g_cam_cur, anyPos);
+        f2 dxy = { xy2.x - xy1.x, xy2.y - xy1.y };
+        float rx = duv.x / dxy.x, ry = duv.y / dxy.x, rz = duv.x / dxy.y, rw = duv.y / dxy.y;   /* :69-72 */
+        if (duv.x == 0.0f)                                          /* :74-75 */
+            rz = rx = 0.0f;
+        /* :76 `if (duv.y = 0.0f)` assigns: never taken */
+        dx.x = fabsf(rx); dx.y = fabsf(ry); dy.x = fabsf(rz); dy.y = fabsf(rw);                 /* :79 */
+    }
+    return tex_grad(tex, UV.x, UV.y, dx, dy);                       /* Model.cu:309 */
+}
+
 /* ---------------------------------------------------------------- pathTracer */
 typedef struct { uint32_t pixel, draw; } rng_t;
 static void rng_uniform4(rng_t *g, float out[4])
@@ -1373,6 +1608,7 @@ int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int widt
         return -1;
     cam_t cam = cam_make(cam_args);
     env_begin(scene);
+    tex_begin(scene, &cam);
     int cw = x1 - x0, ch = y1 - y0;
     uint64_t n_primary = 0, n_shadow = 0, n_bounce = 0;
 #ifdef _OPENMP
@@ -1398,6 +1634,7 @@ int orc_render(const orc_scene *scene, const orc_camera_args *cam_args, int widt
         counts->shadow = n_shadow;
         counts->bounce = n_bounce;
     }
+    tex_end();
     env_end();
     return 0;
 }
@@ -1416,6 +1653,7 @@ int orc_render_pixels(const orc_scene *scene, const orc_camera_args *cam_args, i
             return -1;
     cam_t cam = cam_make(cam_args);
     env_begin(scene);
+    tex_begin(scene, &cam);
     uint64_t n_primary = 0, n_shadow = 0, n_bounce = 0;
 #ifdef _OPENMP
     if (threads > 0)
@@ -1438,6 +1676,7 @@ int orc_render_pixels(const orc_scene *scene, const orc_camera_args *cam_args, i
         counts->shadow = n_shadow;
         counts->bounce = n_bounce;
     }
+    tex_end();
     env_end();
     return 0;
 }
@@ -1485,10 +1724,12 @@ int orc_trace_ray(const orc_scene *scene, const float org[3], const float dir[3]
     ray_t r = mk_ray(mk3(org[0], org[1], org[2]), mk3(dir[0], dir[1], dir[2]));
     rng_t g = { pixel_index, draw0 };
     env_begin(scene);
+    tex_begin(scene, NULL);
     orc_counts c = { 0, 0, 0 };
     float ft = ORC_INF;
     int fp = -1;
     f3 col = path_tracer(scene, r, &g, max_depth, &c, &ft, &fp);
+    tex_end();
     env_end();
     rgb[0] = col.x; rgb[1] = col.y; rgb[2] = col.z;
     if (t) *t = ft;

@@ -21,7 +21,7 @@
  * equality with a real CUDA cuRAND stream is unpinned.
  *
  * Conventions fixed by decision where the reference is racy/undefined
- * (SURVEY.md section 8 hazards H3, H4, H5, H7) are listed in DESIGN.md.
+ * (SURVEY.md section 8 hazards H3, H4, H5, H7, and H9-H13 of the later rows) are listed in DESIGN.md.
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
@@ -73,6 +73,11 @@ typedef struct orc_scene {
     int32_t env_width, env_height;
     const float *env_image;   /* [env_height][env_width][4] floats, as stbi_loadf(.., 4) hands them to
                                  EnvironmentLight(texture, w, h) (kernel.cu:271-272, Light.cuh:108) */
+    const float *tri_uv;      /* [n_tris][3][2] Triangle::vText (Model.cuh:75); NULL = zeros */
+    int32_t n_textures;
+    const int32_t *mesh_texture; /* [n_meshes] the image Mesh::initTexture bound (Model.cu:315-319), -1 = none (H5) */
+    const int32_t *tex_size;  /* [n_textures][2] width, height */
+    const float *tex_data;    /* the images back to back, each [height][width][4] floats (initTexture's data) */
 } orc_scene;
 
 /* The 7 constructor arguments of Camera (reference Camera/Camera.cuh:11). */
@@ -127,6 +132,13 @@ int orc_trace_ray(const orc_scene *scene, const float org[3], const float dir[3]
 /* Philox4x32-10 block and the cuRAND-style float mapping (H7). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void orc_pixel_uniform4(uint32_t pixel_index, uint32_t draw, float out[4]);
+
+/* Mesh textures (Texture/Texture.cu:2-186, H13): number of mip levels of a w x h image, one level of
+ * the chain generateMipMaps builds (out = [lh][lw][4]), and tex2DGrad on the bound texture object. */
+int orc_texture_levels(int w, int h);
+int orc_texture_mip(const float *img, int w, int h, int level, float *out, int *lw, int *lh);
+int orc_tex2d_grad(const float *img, int w, int h, float u, float v, const float dpdx[2],
+                   const float dpdy[2], float rgb[3]);
 
 /* rough2alpha (material.cuh:7-13). */
 float orc_rough2alpha(float rough);

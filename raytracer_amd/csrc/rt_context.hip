@@ -523,6 +523,34 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
         v.env.marg_value = mv; v.env.marg_cdf = mc; v.env.marg_funint = hs.env_marg_funint;
         v.env.w = hs.env_w; v.env.h = hs.env_h; v.env.n = 1;
     }
+    v.tex = TexView{};
+    if (!hs.textures.empty()) {
+        // initImages (Texture.cu:135-186): level 0 from the caller's image (:150-159), the rest of each chain
+        // level by level on the device (generateMipMaps, :48-133)
+        float4 *tdata = nullptr; TexRec *trecs = nullptr; int32_t *mtex = nullptr; TriUv *uv = nullptr;
+        if ((rc = dalloc(c, c->scene_allocs, tdata, hs.tex_texels))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, trecs, hs.textures.size()))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, mtex, hs.mesh_tex.size()))) return rc;
+        if ((rc = dalloc(c, c->scene_allocs, uv, hs.uv.size()))) return rc;
+        RT_HIP(c, up(trecs, hs.textures.data(), hs.textures.size() * sizeof(TexRec)));
+        RT_HIP(c, up(mtex, hs.mesh_tex.data(), hs.mesh_tex.size() * sizeof(int32_t)));
+        RT_HIP(c, up(uv, hs.uv.data(), hs.uv.size() * sizeof(TriUv)));
+        for (size_t k = 0; k < hs.textures.size(); k++) {
+            const TexRec &T = hs.textures[k];
+            RT_HIP(c, up(tdata + T.off[0], hs.tex_level0.data() + 4 * (size_t)hs.tex_level0_at[k],
+                         (size_t)T.w * T.h * sizeof(float4)));
+            int lw = T.w, lh = T.h;
+            for (int l = 1; l < T.levels; l++) {
+                const int nw = std::max(1, lw / 2), nh = std::max(1, lh / 2);
+                launch_mip_level(c->stream, tdata + T.off[l - 1], lw, lh, tdata + T.off[l], nw, nh);
+                lw = nw; lh = nh;
+            }
+        }
+        RT_HIP(c, hipGetLastError());
+        RT_HIP(c, hipStreamSynchronize(c->stream));
+        v.tex.recs = trecs; v.tex.data = (const float *)tdata; v.tex.mesh_tex = mtex; v.tex.uv = uv;
+        v.tex.n = (int)hs.textures.size(); v.tex.n_tri_models = hs.n_tri_models;
+    }
     v.mats = mats;
     v.general = hs.general ? 1 : 0;
     v.tris = tris; v.tri_pos_of = pos_of; v.tri_cold = cold; v.models = models;

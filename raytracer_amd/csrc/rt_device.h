@@ -145,6 +145,8 @@ struct RayPair {
     f2 bestp;         // best * kBestInfl: conservative side of every pre-test
     f2 stop;          // shadow rays: a hit with t below this ends the ray (-1: never)
     int idx, idy;     // reference traversal index of the closest primitive, -1 = none
+    int tidx, tidy;   // traverse<.., LIGHTS> only: the closest TRIANGLE before quadrics and lights were
+                      // tested -- the mesh whose texture colour the record carries (Model.cu:301-310)
     uint32_t oct;     // wave-uniform.  bit 3: every culled ray of the wave runs the same way along
                       // every axis (they share an octant); bits 0-2: towards -x, -y, -z
 };
@@ -815,6 +817,109 @@ __device__ __forceinline__ float env_pdf(const EnvView &e, v3 wi)
         phi = (float)((double)phi + (double)2.0f * kPiD);
     return (float)((double)env_dist_pdf(e, phi * 0.5f * kEnvInvPi, theta * kEnvInvPi) /
                    ((double)2.0f * kPiD * kPiD * (double)sint));
+}
+
+// ------------------------------------------------------------------ mesh textures
+// The texture object of Texture.cu:165-184 in software (DESIGN H13): normalised coordinates, clamp
+// addressing, linear filtering within a level (the tex2D convention of H11 with edge clamping), linear
+// between the two levels nearest lambda = log2(rho), rho from the gradients scaled to level 0's texels.
+__device__ __forceinline__ float4 tex_fetch(const float4 *img, int w, int h, float x, float y)
+{
+    float xb = x * (float)w - 0.5f, yb = y * (float)h - 0.5f;
+    if (!(xb > -1.0f)) xb = -1.0f;                                     // clamp addressing (and NaN)
+    if (xb > (float)w) xb = (float)w;
+    if (!(yb > -1.0f)) yb = -1.0f;
+    if (yb > (float)h) yb = (float)h;
+    float fi = floorf(xb), fj = floorf(yb);
+    float a = floorf((xb - fi) * 256.0f + 0.5f) / 256.0f, b = floorf((yb - fj) * 256.0f + 0.5f) / 256.0f;
+    int i0 = (int)fi, j0 = (int)fj;
+    int i[2] = {min(max(i0, 0), w - 1), min(max(i0 + 1, 0), w - 1)};
+    int j[2] = {min(max(j0, 0), h - 1), min(max(j0 + 1, 0), h - 1)};
+    const float4 t00 = img[(size_t)j[0] * w + i[0]], t10 = img[(size_t)j[0] * w + i[1]];
+    const float4 t01 = img[(size_t)j[1] * w + i[0]], t11 = img[(size_t)j[1] * w + i[1]];
+    auto mix = [&](float c00, float c10, float c01, float c11) {
+        return (1 - a) * (1 - b) * c00 + a * (1 - b) * c10 + (1 - a) * b * c01 + a * b * c11;
+    };
+    float4 r;
+    r.x = mix(t00.x, t10.x, t01.x, t11.x); r.y = mix(t00.y, t10.y, t01.y, t11.y);
+    r.z = mix(t00.z, t10.z, t01.z, t11.z); r.w = mix(t00.w, t10.w, t01.w, t11.w);
+    return r;
+}
+// tex2DGrad<float4>(Texture, x, y, dPdx, dPdy) of Model.cu:309
+__device__ __forceinline__ v3 tex_grad(const TexView &tv, const TexRec &T, float x, float y, float dxx, float dxy,
+                                       float dyx, float dyy)
+{
+    const float ax = dxx * (float)T.w, ay = dxy * (float)T.h, bx = dyx * (float)T.w, by = dyy * (float)T.h;
+    const float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+    float lam = 0.0f;
+    if (rho > 1.0f)
+        lam = fminf((float)log2((double)rho), (float)(T.levels - 1));
+    const float lq = floorf(lam * 256.0f + 0.5f) / 256.0f;
+    int d = (int)floorf(lq);
+    float wgt = lq - (float)d;
+    if (d >= T.levels - 1) {
+        d = T.levels - 1;
+        wgt = 0.0f;
+    }
+    const float4 *base = (const float4 *)tv.data;
+    const float4 c0 = tex_fetch(base + T.off[d], max(1, T.w >> d), max(1, T.h >> d), x, y);
+    if (wgt == 0.0f)
+        return mk3(c0.x, c0.y, c0.z);
+    const float4 c1 = tex_fetch(base + T.off[d + 1], max(1, T.w >> (d + 1)), max(1, T.h >> (d + 1)), x, y);
+    return mk3((1 - wgt) * c0.x + wgt * c1.x, (1 - wgt) * c0.y + wgt * c1.y, (1 - wgt) * c0.z + wgt * c1.z);
+}
+// Camera::getxy (Camera.cu:26-42)
+__device__ __forceinline__ void cam_getxy(const CameraRec &c, v3 poso, float &rx, float &ry)
+{
+    const float step = 0.25f;
+    const v3 dir = normalize(sub(poso, c.pos));
+    rx = 0.0f; ry = 0.0f;
+    if (dot(dir, c.front) == 0.0f)
+        return;
+    const float aspect = (float)c.res_x / c.res_y;
+    const float t = c.n / dot(dir, c.front);
+    const v3 rpos = scale(dir, t);
+    rx = dot(rpos, c.right) * c.res_x / step / aspect;
+    ry = dot(rpos, c.up) * c.res_y / step;
+}
+// Model.cu:304-309 for mesh triangle T (uv = its vText), hit by ray r: Triangle::anyPoint (:60-88),
+// IntersectRecord::getdxdy (IntersectionRecord.cuh:60-80), tex2DGrad on the mesh's image.
+__device__ __forceinline__ v3 mesh_texture_color(const TexView &tv, const TexRec &X, const CameraRec &cam, const TriRec &T,
+                                                 const TriUv &uv, const Ray &r)
+{
+    const v3 &o = r.o, &d = r.d;
+    const float dnd = T.nx * d.x + T.ny * d.y + T.nz * d.z;
+    const float t = (-(o.x * T.nx + o.y * T.ny + o.z * T.nz) + T.dn) / dnd;
+    const v3 Pos = ray_pos(r, t);                                                     // rec.pos, Model.cu:129
+    const v3 ta = mk3(T.ax, T.ay, T.az), tb = mk3(T.bx, T.by, T.bz), tc = mk3(T.cx, T.cy, T.cz);
+    const float s2 = length(cross(sub(Pos, tc), sub(Pos, ta)));
+    const float s3 = length(cross(sub(Pos, tc), sub(Pos, tb)));
+    float m1 = s3 / T.S, m2 = s2 / T.S, m3 = 1.0f - m1 - m2;                          // :67
+    const float U = uv.u0 * m1 + uv.u1 * m2 + uv.u2 * m3, V = uv.v0 * m1 + uv.v1 * m2 + uv.v2 * m3;   // :68 = rec.uv
+    if (m3 > m2) {                                                                    // :69-84 (double literals)
+        if (m3 > m1) {
+            m1 = (float)((double)m1 + 0.01); m2 = (float)((double)m2 + 0.01); m3 = (float)((double)m3 - 0.02);
+        } else {
+            m2 = (float)((double)m2 + 0.01); m3 = (float)((double)m3 + 0.01); m1 = (float)((double)m1 - 0.02);
+        }
+    } else {
+        if (m1 > m2) {
+            m2 = (float)((double)m2 + 0.01); m3 = (float)((double)m3 + 0.01); m1 = (float)((double)m1 - 0.02);
+        } else {
+            m1 = (float)((double)m1 + 0.01); m3 = (float)((double)m3 + 0.01); m2 = (float)((double)m2 - 0.02);
+        }
+    }
+    const float aU = uv.u0 * m1 + uv.u1 * m2 + uv.u2 * m3, aV = uv.v0 * m1 + uv.v1 * m2 + uv.v2 * m3;   // :86
+    const v3 anyPos = add(scale(sub(Pos, ta), m1), scale(sub(Pos, tb), m2));          // :87
+    const float du = aU - U, dv = aV - V;                                             // getdxdy :64
+    float x1, y1, x2, y2;
+    cam_getxy(cam, Pos, x1, y1);
+    cam_getxy(cam, anyPos, x2, y2);
+    const float dx = x2 - x1, dy = y2 - y1;
+    float rx = du / dx, ry = dv / dx, rz = du / dy, rw = dv / dy;                     // :69-72
+    if (du == 0.0f)                                                                   // :74-75 (:76 assigns: never taken)
+        rz = rx = 0.0f;
+    return tex_grad(tv, X, U, V, fabsf(rx), fabsf(ry), fabsf(rz), fabsf(rw));         // Model.cu:309
 }
 
 // black(x) = length(x) < 0.001f (Scene.cu:3-5) and the `length(f) < 0.0001f` of PathTracer.cu:77, without the

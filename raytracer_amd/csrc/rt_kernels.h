@@ -103,6 +103,7 @@ struct DevView {
     const LightRec *lights;         // delta lights (point, then directional)
     const TriLightRec *tlights;     // triangle lights: hit-able (Scene.cu:43-64), sampled with MIS (Scene.cu:242-284)
     EnvView env;                    // the environment light (env.n = 0: none)
+    TexView tex;                    // mesh textures (tex.n = 0: none)
     int n_tris, n_spheres, n_lights, n_tlights;
     // persistent per local pixel
     const uint32_t *pixmap;         // local index -> global pixel index y*W + x
@@ -136,6 +137,8 @@ void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, con
                           const int32_t *first_id, const float *first_t, float4 *rgba,
                           int32_t *prim, float *t);
 void launch_fill_i32(hipStream_t s, int32_t *a, size_t n, int32_t value);
+// d_mipmap (Texture.cu:14-45): level dst (dw x dh) of a mip chain from the level above it (sw x sh)
+void launch_mip_level(hipStream_t s, const float4 *src, int sw, int sh, float4 *dst, int dw, int dh);
 void launch_prepare_rays(hipStream_t s, const RayQueue &q, const float *org, const float *dir,
                          uint32_t n);
 void launch_ishit(hipStream_t s, const float *t, int32_t *ishit, uint32_t n);

@@ -505,6 +505,10 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         __syncthreads();
         merge_in();                              // the block's final answer
     }
+    if (LIGHTS) {
+        r.tidx = r.idx;
+        r.tidy = r.idy;
+    }
     // quadrics come last (Scene.cu:31-37), strict < against the triangles' result
     for (int s = 0; s < A.n_spheres; s++) {
         const SphereRec S = load_uniform(&A.spheres[s]);
@@ -1044,6 +1048,17 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
                 fill_light_hit(v.tlights[id - n_models_prims], r, t, S[h].H);
             else
                 fill_hit(v, r, id, S[h].H);
+            if (v.tex.n) {
+                // Mesh::hit's texture lookup (Model.cu:301-310): the record carries the colour of the last
+                // mesh that updated it -- the mesh of the closest triangle -- also when a quadric or a
+                // light in front of it is what the ray hits (nothing resets rec.color, Model.cu:396-406)
+                const int32_t tid = h ? w.tidy : w.tidx;
+                if (tid >= v.tex.n_tri_models) {
+                    const int32_t tx = v.tex.mesh_tex[v.tri_cold[tid].model - v.tex.n_tri_models];
+                    if (tx >= 0)
+                        S[h].H.color = mesh_texture_color(v.tex, v.tex.recs[tx], v.cam, v.tris[v.tri_pos_of[tid]], v.tex.uv[tid], r);
+                }
+            }
             S[h].wo = neg(r.d);
             lit[h] = !(v.models[S[h].H.model].mat_type & kMatSpecularBit);   // PathTracer.cu:67-70
             if (lit[h])
@@ -2269,6 +2284,28 @@ __global__ void k_ishit(const float *__restrict__ t, int32_t *ishit, uint32_t n)
         ishit[i] = scene_ishit(t[i]) ? 1 : 0;
 }
 
+// d_mipmap (Texture.cu:14-45), one thread per texel of the new level: four bilinear taps of the level
+// above at the texel's corners in normalised coordinates (:30-33), averaged (:36), clamped to 1 (:37).
+// px, py = the `1.0 / float(imageW)` of :19-20, rounded on the host.
+__global__ void k_mip_level(const float4 *__restrict__ src, int sw, int sh, float4 *__restrict__ dst, int dw, int dh,
+                            float px, float py)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint32_t)dw * (uint32_t)dh)
+        return;
+    const uint32_t x = i % (uint32_t)dw, y = i / (uint32_t)dw;
+    const float4 a = tex_fetch(src, sw, sh, (float)(x + 0u) * px, (float)(y + 0u) * py);
+    const float4 b = tex_fetch(src, sw, sh, (float)(x + 1u) * px, (float)(y + 0u) * py);
+    const float4 c = tex_fetch(src, sw, sh, (float)(x + 1u) * px, (float)(y + 1u) * py);
+    const float4 d = tex_fetch(src, sw, sh, (float)(x + 0u) * px, (float)(y + 1u) * py);
+    float4 o;
+    o.x = fminf((a.x + b.x + c.x + d.x) / 4.0f, 1.0f);
+    o.y = fminf((a.y + b.y + c.y + d.y) / 4.0f, 1.0f);
+    o.z = fminf((a.z + b.z + c.z + d.z) / 4.0f, 1.0f);
+    o.w = fminf((a.w + b.w + c.w + d.w) / 4.0f, 1.0f);
+    dst[i] = o;
+}
+
 // ------------------------------------------------------------------ post-process
 // HDRKernel (PostProcess/PostProcess.cuh:29-56): ACES filmic curve + saturate.
 __device__ __forceinline__ float aces1(float x)
@@ -2449,6 +2486,12 @@ void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, con
                                                         prim, t);
 }
 
+void launch_mip_level(hipStream_t s, const float4 *src, int sw, int sh, float4 *dst, int dw, int dh)
+{
+    const float px = (float)(1.0 / (double)(float)dw), py = (float)(1.0 / (double)(float)dh);
+    const size_t n = (size_t)dw * dh;
+    k_mip_level<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, sw, sh, dst, dw, dh, px, py);
+}
 void launch_fill_i32(hipStream_t s, int32_t *a, size_t n, int32_t value)
 {
     if (n)

@@ -256,6 +256,22 @@ struct EnvView {
     int w, h, n;
 };
 
+// Mesh textures (Model.cu:304-319, Texture/Texture.cu:135-186).  One TexRec per image bound with
+// Mesh::initTexture: its mip chain (levels = getMipMapLevels, Texture.cu:2-13; level l + 1 from level l
+// by d_mipmap, :14-45) lies in TexView::data, level l at float4 offset off[l].  uv = Triangle::vText in
+// the reference's traversal order; mesh_tex[j] = the image Mesh j bound, -1 = none (H5).  n = 0: no
+// textures in the scene.
+constexpr int kMaxTexLevels = 16;    // images up to 32768 texels a side
+struct TexRec { uint32_t off[kMaxTexLevels]; int32_t w, h, levels, pad; };
+struct TriUv { float u0, v0, u1, v1, u2, v2; };
+struct TexView {
+    const TexRec *recs;
+    const float *data;
+    const int32_t *mesh_tex;
+    const TriUv *uv;
+    int n, n_tri_models;
+};
+
 // Camera after its constructor (Camera/Camera.cu:4-14); pers/raster2world are dead.
 struct CameraRec {
     v3 pos, up, front, right;

@@ -411,6 +411,49 @@ int build_host_scene(const rt_scene_desc *d, HostScene &out, std::string &err)
         err = "environment light without an image"; return RT_ERR_INVALID;
     }
     out.general = d->n_tri_lights > 0 || d->n_env_lights > 0;
+    // Mesh::initTexture (Model.cu:315-319) -> initImages (Texture.cu:135-186)
+    if (d->n_textures < 0 || (d->n_textures > 0 && (!d->mesh_texture || !d->tex_size || !d->tex_data))) {
+        err = "texture arrays are NULL or their count negative"; return RT_ERR_INVALID;
+    }
+    out.n_tri_models = d->n_tri_models;
+    out.textures.clear(); out.tex_level0.clear(); out.tex_level0_at.clear(); out.mesh_tex.clear(); out.uv.clear();
+    out.tex_texels = 0;
+    if (d->n_textures > 0) {
+        const float *img = d->tex_data;
+        size_t at0 = 0;
+        for (int k = 0; k < d->n_textures; k++) {
+            const int w = d->tex_size[2 * k], h = d->tex_size[2 * k + 1];
+            if (w < 1 || h < 1 || w > 32768 || h > 32768) {
+                err = "texture size must be 1..32768 texels a side"; return RT_ERR_INVALID;
+            }
+            TexRec T{};
+            T.w = w; T.h = h;
+            size_t sz = (size_t)std::max(w, h);                        // getMipMapLevels, Texture.cu:2-13
+            while (sz) { sz /= 2; T.levels++; }
+            int lw = w, lh = h;
+            for (int l = 0; l < T.levels; l++) {
+                if (out.tex_texels > 0xffffffffull - (size_t)lw * lh) { err = "textures too large"; return RT_ERR_UNSUPPORTED; }
+                T.off[l] = (uint32_t)out.tex_texels;
+                out.tex_texels += (size_t)lw * lh;
+                lw = std::max(1, lw / 2); lh = std::max(1, lh / 2);    // Texture.cu:55-58
+            }
+            out.textures.push_back(T);
+            out.tex_level0_at.push_back((uint32_t)at0);
+            out.tex_level0.insert(out.tex_level0.end(), img, img + 4 * (size_t)w * h);
+            at0 += (size_t)w * h;
+            img += 4 * (size_t)w * h;
+        }
+        for (int j = 0; j < d->n_meshes; j++) {
+            if (d->mesh_texture[j] < -1 || d->mesh_texture[j] >= d->n_textures) {
+                err = "mesh_texture out of range"; return RT_ERR_INVALID;
+            }
+            out.mesh_tex.push_back(d->mesh_texture[j]);
+        }
+        out.uv.assign((size_t)d->n_tris, TriUv{});
+        if (d->tri_uv)
+            std::memcpy(out.uv.data(), d->tri_uv, sizeof(TriUv) * (size_t)d->n_tris);
+        out.general = true;
+    }
     for (int m = 0; m < n_models; m++) {
         const int t = d->model_mat_type[m];
         if (t != kMatLambertian && t != kMatFresnel && t != kMatCook && t != kMatGGX && t != kMatOrenNayar) {

@@ -31,6 +31,15 @@ struct HostScene {
     std::vector<MatRec> mats;            // one per ModelRec
     bool general = false;                // non-Lambertian materials or triangle lights
     std::vector<TriLightRec> tlights;    // triangle lights (their Materials: models[n_models + k])
+    // mesh textures: level 0 of every image back to back and where each chain will lie (TexRec); the
+    // other levels are generated on the device (k_mip_level), as the reference does (Texture.cu:48-133)
+    std::vector<TexRec> textures;
+    std::vector<float> tex_level0;       // [sum w h][4]
+    std::vector<uint32_t> tex_level0_at; // float4 offset of each image inside tex_level0
+    size_t tex_texels = 0;               // float4 texels of all chains together
+    std::vector<int32_t> mesh_tex;       // [n_meshes]
+    std::vector<TriUv> uv;               // [n_tris], only with textures
+    int n_tri_models = 0;
 };
 
 // Scene::initializeScene (Scene/Scene.cu:126-202) on the host: validates the flat

@@ -94,7 +94,8 @@ class SceneDesc(C.Structure):
                 ("n_tri_lights", C.c_int32), ("tl_pos", _FP), ("tl_illum", _FP), ("tl_two_side", _IP),
                 ("tl_mat_type", _IP), ("tl_color", _FP), ("model_param", _FP),
                 ("n_env_lights", C.c_int32), ("env_width", C.c_int32), ("env_height", C.c_int32),
-                ("env_image", _FP)]
+                ("env_image", _FP), ("tri_uv", _FP), ("n_textures", C.c_int32), ("mesh_texture", _IP),
+                ("tex_size", _IP), ("tex_data", _FP)]
 
 
 @dataclass
@@ -125,6 +126,12 @@ class SceneData:
     tl_color: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
     # EnvironmentLight(texture, w, h) (Light.cuh:108): [h, w, 4] floats as stbi_loadf(.., 4) returns them; None = no such light
     env_image: np.ndarray = None
+    # Triangle::vText (Model.cuh:75) per triangle; None = zeros
+    tri_uv: np.ndarray = None
+    # Mesh::initTexture(data, w, h) (Model.cu:315-319): the images, [h, w, 4] floats each, and per mesh the index
+    # of the one it bound (-1: none, H5)
+    textures: list = field(default_factory=list)
+    mesh_texture: np.ndarray = None
 
     @property
     def n_tris(self):
@@ -185,6 +192,16 @@ class SceneData:
         if self.env_image is not None:
             self.env_image = np.ascontiguousarray(self.env_image, np.float32)
             assert self.env_image.ndim == 3 and self.env_image.shape[2] == 4
+        if self.tri_uv is not None:
+            self.tri_uv = _f32(self.tri_uv, (n, 3, 2))
+        if self.textures:
+            self.textures = [np.ascontiguousarray(t, np.float32) for t in self.textures]
+            assert all(t.ndim == 3 and t.shape[2] == 4 for t in self.textures)
+            if self.mesh_texture is None:
+                self.mesh_texture = np.full(self.mesh_first.shape[0], -1, np.int32)
+            self.mesh_texture = _i32(self.mesh_texture, (self.mesh_first.shape[0],))
+            self._tex_size = np.array([[t.shape[1], t.shape[0]] for t in self.textures], np.int32)
+            self._tex_data = np.concatenate([t.reshape(-1) for t in self.textures]).astype(np.float32)
         assert self.pl_pos.shape == self.pl_illum.shape
         assert self.dl_dir.shape == self.dl_illum.shape
         assert self.quad_type.shape[0] == self.quad_coeff.shape[0]
@@ -216,6 +233,11 @@ class SceneData:
             d.n_env_lights = 1
             d.env_height, d.env_width = int(self.env_image.shape[0]), int(self.env_image.shape[1])
             d.env_image = fp(self.env_image)
+        if self.tri_uv is not None:
+            d.tri_uv = fp(self.tri_uv)
+        if self.textures:
+            d.n_textures = len(self.textures)
+            d.mesh_texture, d.tex_size, d.tex_data = ip(self.mesh_texture), ip(self._tex_size), fp(self._tex_data)
         return d
 
 
@@ -225,7 +247,8 @@ class SceneBuilder:
 
     def __init__(self):
         self._tris = []      # (pos[3,3], nrm[3,3], xf, color)
-        self._meshes = []    # (pos[n,3,3], nrm[n,3,3], xf, color)
+        self._meshes = []    # (pos[n,3,3], nrm[n,3,3], xf, color, uv[n,3,2] or None, texture index or -1)
+        self._textures = []
         self._quads = []     # (coeff, type, xf, color)
         self._lights = []
         self._dir_lights = []
@@ -236,10 +259,17 @@ class SceneBuilder:
                            identity() if xf is None else _f32(xf, (4, 4)), color))
         return self
 
-    def add_mesh(self, pos, nrm, xf=None, color=(0.7, 0.7, 0.7)):
+    def add_mesh(self, pos, nrm, xf=None, color=(0.7, 0.7, 0.7), uv=None, texture=None):
+        """A Mesh as readFile leaves it (Model.cu:139-284); ``uv`` = its triangles' vText, ``texture`` = the
+        [h, w, 4] float image Mesh::initTexture binds (Model.cu:315-319)."""
         pos = _f32(pos, (-1, 3, 3))
+        tex = -1
+        if texture is not None:
+            self._textures.append(np.ascontiguousarray(texture, np.float32))
+            tex = len(self._textures) - 1
         self._meshes.append((pos, _f32(nrm, pos.shape),
-                             identity() if xf is None else _f32(xf, (4, 4)), color))
+                             identity() if xf is None else _f32(xf, (4, 4)), color,
+                             None if uv is None else _f32(uv, (pos.shape[0], 3, 2)), tex))
         return self
 
     def add_sphere(self, coeff_x, xf=None, color=(0.7, 0.7, 0.7)):
@@ -266,14 +296,15 @@ class SceneBuilder:
     def build(self) -> SceneData:
         s = SceneData()
         s.n_tri_models = len(self._tris)
-        pos, nrm, model, xf, col = [], [], [], [], []
+        pos, nrm, model, xf, col, uvs = [], [], [], [], [], []
         for i, (p, n, m, c) in enumerate(self._tris):
             pos.append(p[None]); nrm.append(n[None]); model.append(np.full(1, i, np.int32))
-            xf.append(m); col.append(c)
+            xf.append(m); col.append(c); uvs.append(np.zeros((1, 3, 2), np.float32))
         first, count = [], []
         cursor = len(self._tris)
-        for j, (p, n, m, c) in enumerate(self._meshes):
+        for j, (p, n, m, c, uv, _) in enumerate(self._meshes):
             pos.append(p); nrm.append(n)
+            uvs.append(np.zeros((p.shape[0], 3, 2), np.float32) if uv is None else uv)
             model.append(np.full(p.shape[0], s.n_tri_models + j, np.int32))
             first.append(cursor); count.append(p.shape[0]); cursor += p.shape[0]
             xf.append(m); col.append(c)
@@ -297,4 +328,8 @@ class SceneBuilder:
         s.tl_two_side = np.array([l[2] for l in self._tri_lights], np.int32)
         s.tl_mat_type = np.full(len(self._tri_lights), MAT_LAMBERTIAN, np.int32)
         s.tl_color = np.array([l[3] for l in self._tri_lights], np.float32).reshape(-1, 3)
+        if self._textures:
+            s.tri_uv = np.concatenate(uvs)
+            s.textures = list(self._textures)
+            s.mesh_texture = np.array([m[5] for m in self._meshes], np.int32)
         return s.normalise()

@@ -411,3 +411,60 @@ def material_test_scene(seed=7):
 
 
 CONFIGS = {"c1": c1, "c2": c2, "c3": c3, "c4": c4, "c5": c5}
+
+
+def synthetic_texture(width, height, seed, peak=1.0):
+    """A seeded [h, w, 4] float image for Mesh::initTexture (Model.cu:315-319): a checker over smooth colour
+    ramps plus noise; ``peak`` > 1 puts texels above the 1.0 that d_mipmap clamps averaged levels to
+    (Texture.cu:37)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    img = np.zeros((height, width, 4), np.float32)
+    check = ((xx // max(1, width // 8) + yy // max(1, height // 4)) % 2).astype(np.float32)
+    img[..., 0] = 0.15 + 0.7 * check
+    img[..., 1] = 0.1 + 0.8 * xx / max(1, width - 1)
+    img[..., 2] = 0.9 - 0.7 * yy / max(1, height - 1)
+    img[..., :3] += rng.uniform(0.0, 0.1, (height, width, 3)).astype(np.float32)
+    img[..., :3] *= peak
+    img[..., 3] = 1.0
+    return img
+
+
+def textured_test_scene(seed=7):
+    """material_test_scene with mesh textures (Model.cu:60-88,304-309, Texture/*): the
+    Oren-Nayar blob carries a 64x32 image through uv from its vertex normals, the Cook-Torrance ground a
+    5x7 one (not a power of two, texels above 1) through uv that leave [0, 1] (clamp addressing); a third,
+    untextured mesh stands in front of part of the ground (its hits put the record's colour back to the
+    BRDF's own, H5), and the spheres in front of the meshes inherit the colour of the mesh behind them
+    (nothing resets rec.color, Model.cu:396-406)."""
+    from .scene import MAT_COOK, MAT_FRESNEL, MAT_GGX, MAT_LAMBERTIAN, MAT_OREN_NAYAR
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    b.add_triangle([(-400, -120, -900), (400, -120, -900), (0, 500, -900)], [(0, 0, 1)] * 3,
+                   identity(), (0.7, 0.6, 0.5))
+    b.add_triangle([(-60, -20, -300), (10, -25, -310), (-20, 50, -290)],
+                   [(0.1, 0.0, 1.0), (0.0, 0.1, 1.0), (-0.1, 0.0, 1.0)], translation(15, 5, -40),
+                   (0.2, 0.7, 0.3))
+    p, n = blob_mesh(14, 10, 1.0, seed)
+    d = p / np.linalg.norm(p, axis=2, keepdims=True)
+    uv = np.stack([0.5 + np.arctan2(d[..., 0], d[..., 2]) / (2 * np.pi), 0.5 + np.arcsin(d[..., 1]) / np.pi], axis=2)
+    xf = translation(60.0, 10.0, -420.0) @ scale(55.0, 45.0, 50.0)
+    b.add_mesh(p, n, xf.astype(np.float32), (0.7, 0.7, 0.7), uv=uv, texture=synthetic_texture(64, 32, seed + 1))
+    gp, gn = grid_mesh(9, 7, -300, 300, -800, -150, -110.0, seed=seed, amp=25.0)
+    guv = np.stack([(gp[..., 0] + 260.0) / 480.0, (gp[..., 2] + 760.0) / 520.0], axis=2)     # leaves [0, 1] at the rim
+    b.add_mesh(gp, gn, identity(), (0.6, 0.6, 0.7), uv=guv, texture=synthetic_texture(5, 7, seed + 2, peak=1.6))
+    wp, wn = _box((-230.0, -120.0, -520.0), (-150.0, -40.0, -440.0))
+    b.add_mesh(wp, wn, identity(), (0.3, 0.8, 0.4))                                          # no texture
+    b.add_sphere(1.0 / 40.0, translation(-110.0, -40.0, -380.0), (0.7, 0.2, 0.1))
+    b.add_sphere(1.0 / 25.0, translation(20.0, -70.0, -260.0), (0.3, 0.3, 0.8))
+    b.add_point_light((-300.0, 300.0, -100.0), (1.5e5, 1.25e5, 1.0e5))
+    b.add_point_light((250.0, 150.0, -200.0), (0.5e5, 0.75e5, 1.0e5))
+    b.add_directional_light((0.6, -0.35, -0.7), (0.5, 0.45, 0.4))
+    b.add_triangle_light([(150.0, -60.0, -330.0), (190.0, 90.0, -350.0), (120.0, 60.0, -300.0)], (60.0, 90.0, 140.0),
+                         two_side=True, color=(0.5, 0.6, 0.9))
+    scene = b.build()
+    #                                tri 0           tri 1    blob            ground    box             sphere 0  sphere 1
+    scene.model_mat_type = np.int32([MAT_LAMBERTIAN, MAT_GGX, MAT_OREN_NAYAR, MAT_COOK, MAT_LAMBERTIAN, MAT_GGX, MAT_FRESNEL])
+    scene.model_param = np.float32([[0, 0], [0.35, 0], [0, 0], [0.6, 0], [0, 0], [0.2, 0], [0, 1.5]])
+    scene.model_color[6] = (0.95, 0.95, 0.95)
+    return scene.normalise(), rng

@@ -47,6 +47,8 @@ CASES = {
     # scene under one: EnvironmentLight + Distribution2D
     "demo_env": (("demo_env", {}), 160, 120, (40, 20, 120, 100), [(2, 0), (3, 6)]),
     "materials_env": (("materials_env", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 6)]),
+    # mesh textures with mip LOD: the materials scene with two textured meshes
+    "textured": (("textured", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (3, 6)]),
 }
 
 
@@ -54,7 +56,7 @@ SCENE_FIELDS = ["tri_pos", "tri_nrm", "tri_model", "mesh_first", "mesh_count", "
                 "model_mat_type", "model_color", "quad_coeff", "quad_type", "pl_pos", "pl_illum"]
 OPTIONAL_SCENE_FIELDS = ["dl_dir", "dl_illum",        # absent from fixtures written before them
                          "tl_pos", "tl_illum", "tl_two_side", "tl_mat_type", "tl_color",
-                         "model_param", "env_image"]
+                         "model_param", "env_image", "tri_uv", "mesh_texture"]
 
 
 def load_case(name):
@@ -68,6 +70,10 @@ def load_case(name):
     for f in OPTIONAL_SCENE_FIELDS:
         if "scene_" + f in z:
             setattr(scene, f, z["scene_" + f])
+    k = 0
+    while f"scene_texture_{k}" in z:                       # Mesh::initTexture images
+        scene.textures.append(z[f"scene_texture_{k}"])
+        k += 1
     scene.normalise()
     c = json.loads(str(z["camera"]))
     cam = CameraArgs(pos=tuple(c["pos"]), lookat=tuple(c["lookat"]), fov=c["fov"], near=c["near"],
@@ -78,9 +84,10 @@ def load_case(name):
 
 def build_case(name):
     (kind, kw), w, h, crop, runs = CASES[name]
-    if kind in ("mixed", "sun", "area", "materials"):
+    if kind in ("mixed", "sun", "area", "materials", "textured"):
         scene, _ = {"mixed": scenes.mixed_test_scene, "sun": scenes.sun_test_scene,
-                    "area": scenes.area_test_scene, "materials": scenes.material_test_scene}[kind]()
+                    "area": scenes.area_test_scene, "materials": scenes.material_test_scene,
+                    "textured": scenes.textured_test_scene}[kind]()
         cam = CameraArgs.for_image(w, h, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
     elif kind == "materials_env":
         scene, _ = scenes.material_test_scene()
@@ -113,6 +120,8 @@ def main():
         for f in SCENE_FIELDS + OPTIONAL_SCENE_FIELDS:
             if getattr(scene, f) is not None:
                 out["scene_" + f] = getattr(scene, f)
+        for ti, img in enumerate(scene.textures):
+            out[f"scene_texture_{ti}"] = img
         out["scene_n_tri_models"] = np.array(scene.n_tri_models)
         out["camera"] = np.array(json.dumps(dict(pos=cam.pos, lookat=cam.lookat, fov=cam.fov,
                                                  near=cam.near, far=cam.far, res=cam.res,

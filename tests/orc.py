@@ -53,6 +53,9 @@ def lib():
         L.orc_tonemap_aces.argtypes = [C.c_int, FP, FP]
         L.orc_median3x3.argtypes = [C.c_int, C.c_int, FP, FP]
         L.orc_num_threads.restype = C.c_int
+        L.orc_texture_levels.argtypes = [C.c_int, C.c_int]
+        L.orc_texture_mip.argtypes = [FP, C.c_int, C.c_int, C.c_int, FP, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_tex2d_grad.argtypes = [FP, C.c_int, C.c_int, C.c_float, C.c_float, FP, FP, FP]
         _lib = L
     return _lib
 
@@ -161,3 +164,26 @@ def median3x3(rgba):
     out = np.zeros_like(rgba)
     lib().orc_median3x3(w, h, _fp(rgba), _fp(out))
     return out
+
+
+def texture_levels(w, h):
+    return lib().orc_texture_levels(w, h)
+
+
+def texture_mip(img, level):
+    """Level `level` of the mip chain generateMipMaps builds over img[h, w, 4] (Texture.cu:48-133)."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    lw, lh = C.c_int(), C.c_int()
+    assert lib().orc_texture_mip(_fp(img), w, h, level, None, C.byref(lw), C.byref(lh)) == 0
+    out = np.zeros((lh.value, lw.value, 4), np.float32)
+    assert lib().orc_texture_mip(_fp(img), w, h, level, _fp(out), None, None) == 0
+    return out
+
+
+def tex2d_grad(img, u, v, dpdx=(0.0, 0.0), dpdy=(0.0, 0.0)):
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape[:2]
+    dx, dy, rgb = np.float32(dpdx), np.float32(dpdy), np.zeros(3, np.float32)
+    assert lib().orc_tex2d_grad(_fp(img), w, h, u, v, _fp(dx), _fp(dy), _fp(rgb)) == 0
+    return rgb

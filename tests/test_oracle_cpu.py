@@ -284,3 +284,76 @@ def test_environment_light_emission_and_sampling():
     # (not black below: Distribution::sample returns offset + fraction, PiecewiseConstant.cu:39, so the sampled
     # theta = sample.y * pi wraps around the sphere many times, Light.cu:140)
     assert lit > 0.5 and lit > 3.0 * unlit
+
+
+# ----------------------------------------------------------------------------- mesh textures (N4)
+def test_texture_mip_chain_and_filter():
+    """initImages / generateMipMaps (Texture.cu:2-13,48-186) and the software tex2DGrad (DESIGN H13):
+    level count and sizes, a constant image stays constant down the chain, averaged texels above 1 are
+    clamped (Texture.cu:37), a 2x2 box average where the taps land on texel centres' midpoints, edge
+    clamping, and the level the gradients select."""
+    assert [orc.texture_levels(w, h) for w, h in [(1, 1), (2, 2), (5, 7), (64, 32), (1024, 3)]] == [1, 2, 3, 7, 11]
+    img = np.full((7, 5, 4), 0.25, np.float32)
+    for lvl, (lh, lw) in enumerate([(7, 5), (3, 2), (1, 1)]):
+        m = orc.texture_mip(img, lvl)
+        assert m.shape == (lh, lw, 4) and np.all(m == np.float32(0.25))
+    hot = np.full((4, 4, 4), 3.0, np.float32)
+    assert np.all(orc.texture_mip(hot, 0) == 3.0) and np.all(orc.texture_mip(hot, 1) == 1.0)
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 0.9, (8, 8, 4)).astype(np.float32)
+    m1 = orc.texture_mip(img, 1)
+    # tap x of the 4x4 level reads the 8x8 one at texel coordinate 2x - 0.5: the mean of texels 2x-1 and 2x
+    # (clamped at the edge); taps x and x + 1 together cover texels 2x-1 .. 2x+2 with equal weights
+    pad = np.pad(img, ((1, 1), (1, 1), (0, 0)), mode="edge")
+    want = np.zeros_like(m1)
+    for y in range(4):
+        for x in range(4):
+            want[y, x] = pad[2 * y:2 * y + 4, 2 * x:2 * x + 4].astype(np.float64).mean(axis=(0, 1))
+    assert np.allclose(m1, want, rtol=0, atol=2e-7)
+    # texel centres return the texel; coordinates outside [0, 1] clamp to the edge texel
+    assert np.array_equal(orc.tex2d_grad(img, (3 + 0.5) / 8, (5 + 0.5) / 8), img[5, 3, :3])
+    assert np.array_equal(orc.tex2d_grad(img, -0.7, 1.9), img[7, 0, :3])
+    assert np.array_equal(orc.tex2d_grad(img, float("nan"), 0.5 / 8), img[0, 0, :3])
+    # gradients of one texel per pixel or less: level 0; two texels: level 1; huge or infinite: the 1x1 level
+    c = (0.4, 0.6)
+    lvl = [orc.tex2d_grad(orc.texture_mip(img, l), *c) for l in range(4)]
+    assert np.array_equal(orc.tex2d_grad(img, *c, (1 / 8, 0), (0, 1 / 8)), lvl[0])
+    assert np.array_equal(orc.tex2d_grad(img, *c, (2 / 8, 0), (0, 0.1 / 8)), lvl[1])
+    assert np.array_equal(orc.tex2d_grad(img, *c, (0, 0), (float("inf"), 0)), lvl[3])
+    assert np.array_equal(orc.tex2d_grad(img, *c, (float("nan"), 0), (0, 0)), lvl[0])
+    mid = orc.tex2d_grad(img, *c, (2 ** 0.5 / 8, 0), (0, 0))                  # lambda = 0.5
+    assert np.allclose(mid, 0.5 * lvl[0] + 0.5 * lvl[1], atol=1e-7)
+
+
+def test_mesh_texture_colours_the_record():
+    """Mesh::hit's lookup (Model.cu:301-310): a textured mesh's hit is shaded with the texel, not the BRDF's
+    colour; a sphere in front of it inherits that colour (nothing resets rec.color); an untextured mesh in
+    front resets it (H5)."""
+    from raytracer_amd.scene import SceneBuilder
+    tex = np.zeros((4, 4, 4), np.float32)
+    tex[..., 0], tex[..., 3] = 1.0, 1.0                                       # pure red everywhere
+    quad_p = np.float32([[(-50, -50, -100), (50, -50, -100), (50, 50, -100)], [(-50, -50, -100), (50, 50, -100), (-50, 50, -100)]])
+    quad_n = np.float32([[(0, 0, 1)] * 3] * 2)
+    quad_uv = np.float32([[(0, 0), (1, 0), (1, 1)], [(0, 0), (1, 1), (0, 1)]])
+
+    def scene(sphere=False, cover=False, textured=True):
+        b = SceneBuilder()
+        b.add_mesh(quad_p, quad_n, color=(0.0, 1.0, 0.0), uv=quad_uv, texture=tex if textured else None)
+        if cover:
+            b.add_mesh(quad_p * np.float32([0.2, 0.2, 0.5]), quad_n, color=(0.0, 0.0, 1.0))
+        if sphere:
+            b.add_sphere(1.0 / 5.0, scenes_translation(0.0, 0.0, -40.0), color=(0.0, 0.0, 1.0))
+        b.add_point_light((0.0, 0.0, 0.0), (1.0e4, 1.0e4, 1.0e4))
+        return b.build()
+
+    from raytracer_amd.scene import translation as scenes_translation
+    cam = CameraArgs.for_image(128, 128)
+    centre = lambda s: orc.render(s, cam, 128, 128, spp=1, max_depth=0, crop=(64, 64, 65, 65))["rgba"][0, 0, :3]
+    plain, red = centre(scene(textured=False)), centre(scene())
+    assert plain[1] > 0 and plain[0] == 0 and plain[2] == 0                   # the BRDF's green
+    assert red[0] > 0 and red[1] == 0 and red[2] == 0                         # the texture's red
+    ball = centre(scene(sphere=True))
+    assert ball[0] > 0 and ball[1] == 0 and ball[2] == 0                      # blue sphere shaded red
+    assert centre(scene(sphere=True, textured=False))[2] > 0
+    cover = centre(scene(cover=True))
+    assert cover[2] > 0 and cover[0] == 0                                     # untextured mesh in front: its own blue

@@ -826,6 +826,62 @@ def test_material_parameters_are_required(gpu_ctx_factory):
     assert rc == abi.RT_ERR_INVALID
 
 
+# ----------------------------------------------------------------------------- mesh textures (N4)
+def test_textured_meshes_full_frames(gpu_ctx_factory):
+    """Mesh textures with mip LOD (Model.cu:60-88,304-309, Texture/Texture.cu): the mip chain built on the
+    device (k_mip_level = d_mipmap) and the software tex2DGrad (DESIGN H13) against the oracle's, whole
+    frames with ray counts at depth 0 and with bounces, every BRDF taking the texel as its colour; spheres
+    in front of a textured mesh inherit its colour; tree == scan bit for bit; a partition's pixels equal
+    the full frame's."""
+    scene, _ = scenes.textured_test_scene()
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    for spp, depth in [(2, 0), (3, 6)]:
+        got, ref, st = render_both(gpu_ctx_factory, scene, cam, 96, 64, spp, depth)
+        check_images(got, ref, st)
+        assert st.batch_launches == 0
+    import copy
+    plain = copy.deepcopy(scene)
+    plain.textures, plain.mesh_texture = [], None
+    base = orc.render(plain, cam, 96, 64, spp=3, max_depth=6)
+    changed = np.abs(base["rgba"] - ref["rgba"])[..., :3].max(axis=2) > 1e-6
+    for lo, hi in [(2, 282), (282, 408), (scene.n_tris, scene.n_tris + 1)]:      # blob, ground, a sphere in front
+        seen = (got["prim_id"] >= lo) & (got["prim_id"] < hi)
+        assert (seen & changed).sum() > 20
+    ctx = gpu_ctx_factory(96, 64)
+    ctx.upload_scene(scene)
+    ctx.set_camera(cam)
+    ctx.set_culling(0)
+    ctx.render(1, 6)
+    ctx.render(2, 6)
+    scan = ctx.read_framebuffer()
+    assert np.array_equal(scan["rgba"].view(np.uint32), got["rgba"].view(np.uint32))
+    part = gpu_ctx_factory(96, 64)
+    part.upload_scene(scene)
+    part.set_camera(cam)
+    part.set_partition(1, 3, 16)
+    part.render(3, 6)
+    sub = part.read_framebuffer()
+    mine = sub["prim_id"] != -2
+    assert mine.sum() > 1000
+    assert np.array_equal(sub["rgba"][mine].view(np.uint32), got["rgba"][mine].view(np.uint32))
+
+
+def test_texture_upload_limits(gpu_ctx_factory):
+    import ctypes as C
+    scene, _ = scenes.textured_test_scene()
+    ctx = gpu_ctx_factory(8, 8)
+    d = scene.desc()
+    d.tex_data = C.POINTER(C.c_float)()
+    assert abi.lib().rt_upload_scene(ctx._h, C.byref(d)) == abi.RT_ERR_INVALID
+    scene.mesh_texture = np.int32([0, 2, -1])                   # only two images
+    with pytest.raises(abi.RtError) as e:
+        ctx.upload_scene(scene)
+    assert e.value.code == abi.RT_ERR_INVALID
+    scene.mesh_texture = np.int32([1, -1, 0])                   # any mesh may bind any image; NULL uv = zeros
+    scene.tri_uv = None
+    ctx.upload_scene(scene)
+
+
 # ----------------------------------------------------------------------------- environment light (N3)
 def test_reference_demo_scene_with_environment(gpu_ctx_factory):
     """The reference's demo scene whole (kernel.cu:268-313): two spheres, a two-sided triangle light

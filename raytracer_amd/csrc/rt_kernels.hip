@@ -604,6 +604,7 @@ struct PathArgs {
     Ctl *ctl;
     ChunkFeedback fb;
     uint32_t heavy_x4;               // heavy = cost >= heavy_x4 / 4 times the mean chunk cost
+    bool regen;                      // general kernel: dead slots take new pixels at once (see general_wave)
 };
 // Per-launch values every chunk shares (kept apart from the kernel argument block, which
 // stays read-only in the constant address space).
@@ -947,7 +948,21 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
 //     on (PathTracer.cu:31-52 run before the break of :64);
 //   * no occlusion shortcut and no LDS stash: this is the feature path, kept plain.  The bench
 //     configurations never come here.
+// Paths of one wave end at very different bounces (most camera rays leave the scene, a few bounce
+// to the depth limit), and an iteration costs the same however few of its 128 slots are alive.  So
+// the wave is persistent and, over a shallow tree (A.regen), REGENERATES paths: a slot whose path
+// has ended takes the next pixel of the wave's current chunk (a new chunk from the dispenser when
+// that is used up) and starts its camera ray in the same iteration in which its neighbours trace
+// their bounce rays; the bounce number is per slot.  Which slot renders a pixel does not matter to
+// the result: the RNG stream and the running mean are the pixel's own.  Over a deeper tree a wave's
+// traversal costs what the union of its rays visits, and camera rays from two distant chunks visit
+// twice as much as those of one (measured: -25 % on the 410-triangle test scenes), so there the wave
+// takes a whole new chunk only when all of its slots are dead.  The wave leaves when the dispensers
+// are empty and all of its slots are dead -- every path ends after at most max_depth + 2 iterations.
+// Chunks come from one dispenser per XCD, each over its own eighth of the range first (a band of the
+// image, hence a part of the tree its L2 can hold), the others' when that is used up.
 struct GeneralState {
+    int bounce;                      // PathTracer.cu:25 `bounces` of this slot's path
     uint32_t draw0;                  // Philox draw of this bounce's tmp (PathTracer.cu:27); light q draws draw0 + 1 + q
     v3 wo;                           // -r.dir of the ray that found the hit
     Hit H;
@@ -961,7 +976,8 @@ struct GeneralState {
 };
 
 template <bool CULL>
-__device__ __forceinline__ void path_chunk_general(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane)
+__device__ __forceinline__ void general_wave(const PathArgs &A, const ChunkEnv &env, uint32_t *__restrict__ work,
+                                             uint32_t n_chunks, uint32_t lane)
 {
     const DevView &v = A.v;
     const int Ld = v.n_lights, La = v.n_tlights, Ne = v.env.n, L = Ld + La + Ne;
@@ -969,10 +985,32 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
     const float E = A.T.tv.extent;
     uint32_t cost = 0, n_shadow = 0, n_bounce = 0;
     Stamps sp0;
-    auto pixel_of = [&](int h) { return A.p0 + min(chunk * kPathChunk + (uint32_t)h * 64u + lane, A.n - 1u); };
-    bool mine[2], alive[2], lit[2] = {false, false}, ishit[2] = {false, false}, cast[2] = {false, false};
+    uint32_t pl[2] = {A.p0, A.p0};                           // local pixel of the slot's path
+    auto pixel_of = [&](int h) { return pl[h]; };
+    bool alive[2] = {false, false}, lit[2] = {false, false}, ishit[2] = {false, false}, cast[2] = {false, false};
     GeneralState S[2];
-    uint32_t draw[2];
+    uint32_t draw[2] = {0u, 0u};
+    uint32_t q_next = 0u, q_end = 0u;                        // wave-uniform: pixels of the current chunk not handed out yet
+    bool exhausted = false;
+    // (regenerating waves share one dispenser: no tree to keep in an L2, and image bands of unequal cost
+    // would only leave XCDs waiting for one another -- measured on the reference's demo scene)
+    const uint32_t per = A.regen ? n_chunks : (n_chunks + 7u) / 8u, xcd = A.regen ? 0u : blockIdx.x & 7u;
+    uint32_t stage = 0u;                                     // dispenser (xcd + stage) & 7 is the one in use
+    auto next_chunk = [&]() -> uint32_t {                    // wave-uniform; n_chunks: none left
+        for (; stage < 8u; stage++) {
+            const uint32_t y = (xcd + stage) & 7u, base = y * per;
+            const uint32_t size = base < n_chunks ? min(per, n_chunks - base) : 0u;
+            if (!size)
+                continue;
+            uint32_t d = 0u;
+            if (lane == 0)
+                d = atomicAdd(&work[y], 1u);
+            d = __builtin_amdgcn_readfirstlane(d);
+            if (d < size)
+                return base + d;
+        }
+        return n_chunks;
+    };
     const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
     RayPair w;
     auto trace = [&](const v3 o[2], const v3 d[2], const bool live[2]) {
@@ -990,25 +1028,54 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
         return (sid >= v.n_tris && sid < n_models_prims) ? hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best)
                                                          : ray_pos(sr, best);
     };
-    v3 ro[2], rd[2];
+    v3 ro[2] = {mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)}, rd[2] = {mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)};
+    S[0] = GeneralState{}; S[1] = GeneralState{};
+    auto end_path = [&](int h) {                             // kernel.cu:75-77, and the stream's position for the next sample
+        finalize_path(v, pl[h], S[h].res);
+        v.rng_ctr[pl[h]] = draw[h];
+        alive[h] = false;
+    };
+    for (;;) {
+        // ---- dead slots take the next pixels (kernel.cu:50-74 up to the call of pathTracer)
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        mine[h] = chunk * kPathChunk + (uint32_t)h * 64u + lane < A.n;
-        alive[h] = mine[h];
-        const uint32_t p = pixel_of(h), pix = v.pixmap[p];
-        float u[4];
-        draw[h] = v.rng_ctr[p];
-        pixel_uniform4(pix, draw[h], u);                     // kernel.cu:67 (H4)
-        draw[h] += 1u;
-        int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
-        Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
-        ro[h] = r.o; rd[h] = r.d;
-        S[h] = GeneralState{};
-        S[h].beta = mk3(1.0f, 1.0f, 1.0f);
-        S[h].res = mk3(0.0f, 0.0f, 0.0f);
-        S[h].wi = mk3(0.0f, 0.0f, 0.0f);                     // H9
-    }
-    for (int bounce = 0;; bounce++) {
+        for (int h = 0; h < 2; h++) {
+            unsigned long long dead = __ballot(!alive[h]);
+            if (!A.regen && (__ballot(alive[0]) | __ballot(alive[1])) && q_next == q_end)
+                break;                                       // a whole new chunk, once every slot is dead
+            while (dead && !exhausted) {
+                if (q_next == q_end) {
+                    const uint32_t d = next_chunk();
+                    if (d >= n_chunks) {
+                        exhausted = true;
+                        break;
+                    }
+                    q_next = d * kPathChunk;
+                    q_end = min(q_next + kPathChunk, A.n);
+                }
+                const uint32_t rank = (uint32_t)__popcll(dead & ((1ull << lane) - 1ull));
+                const uint32_t avail = q_end - q_next;
+                if (!alive[h] && rank < avail) {
+                    pl[h] = A.p0 + q_next + rank;
+                    const uint32_t p = pl[h], pix = v.pixmap[p];
+                    float u[4];
+                    draw[h] = v.rng_ctr[p];
+                    pixel_uniform4(pix, draw[h], u);         // kernel.cu:67 (H4)
+                    draw[h] += 1u;
+                    int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
+                    Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
+                    ro[h] = r.o; rd[h] = r.d;
+                    S[h] = GeneralState{};
+                    S[h].beta = mk3(1.0f, 1.0f, 1.0f);
+                    S[h].res = mk3(0.0f, 0.0f, 0.0f);
+                    S[h].wi = mk3(0.0f, 0.0f, 0.0f);         // H9
+                    alive[h] = true;
+                }
+                q_next += min((uint32_t)__popcll(dead), avail);
+                dead = __ballot(!alive[h]);
+            }
+        }
+        if (!(__ballot(alive[0]) | __ballot(alive[1])))
+            break;                                           // nothing left to hand out, every path ended
         // ---- closest hit of this bounce: PathTracer.cu:27-64
         trace(ro, rd, alive);
 #pragma unroll
@@ -1021,6 +1088,7 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
             if (!alive[h])
                 continue;
             const uint32_t p = pixel_of(h);
+            const int bounce = S[h].bounce;
             if (bounce == 0) {
                 v.first_id[p] = id;
                 v.first_t[p] = t;
@@ -1033,15 +1101,13 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
                 S[h].res = add(S[h].res, mul(S[h].beta, env_L(v.env, r.d)));
             if (S[h].last) {                                 // traced for its emission only: the break of :64
                 ishit[h] = false;
-                finalize_path(v, p, S[h].res);
-                alive[h] = false;
+                end_path(h);
                 continue;
             }
             S[h].draw0 = draw[h];
             draw[h] += 1u;                                   // tmp (PathTracer.cu:27)
             if (!ishit[h]) {                                 // PathTracer.cu:64
-                finalize_path(v, p, S[h].res);
-                alive[h] = false;
+                end_path(h);
                 continue;
             }
             if (on_light)
@@ -1316,6 +1382,7 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
             if (!ishit[h])
                 continue;
             const uint32_t p = pixel_of(h);
+            const int bounce = S[h].bounce;
             if (lit[h])
                 S[h].res = add(S[h].res, mul(S[h].beta, S[h].le));       // PathTracer.cu:73
             const Hit &H = S[h].H;
@@ -1347,22 +1414,15 @@ __device__ __forceinline__ void path_chunk_general(const PathArgs &A, const Chun
                 else
                     done = true;
             }
-            if (done) {
-                finalize_path(v, p, S[h].res);
-                alive[h] = false;
-            }
+            if (done)
+                end_path(h);
+            else
+                S[h].bounce = bounce + 1;
             ishit[h] = false;
             lit[h] = false;
         }
-        const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]);
-        if (!(a0 | a1))
-            break;
-        n_bounce += (uint32_t)__popcll(a0) + (uint32_t)__popcll(a1);
+        n_bounce += (uint32_t)__popcll(__ballot(alive[0])) + (uint32_t)__popcll(__ballot(alive[1]));
     }
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-        if (mine[h])
-            v.rng_ctr[pixel_of(h)] = draw[h];
     if (lane == 0) {
         if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
         if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
@@ -1485,15 +1545,15 @@ template <bool CULL>
 __global__ __launch_bounds__(kBlock, 1) void k_path_general(const PathArgs A, uint32_t *__restrict__ work,
                                                          uint32_t *__restrict__ work_next, int dynamic)
 {
-    __shared__ uint32_t s_chunk;
+    (void)dynamic;                   // always the dispenser: a wave asks for pixels whenever slots fall free
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
-    ChunkEnv env;
+    ChunkEnv env{};
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
-    run_chunks<CULL>(
-        n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t chunk) { path_chunk_general<CULL>(A, env, chunk, lane); },
-        [&](uint32_t chunk) { path_chunk_general<CULL>(A, env, chunk, lane); });   // (never: no feedback here)
+    env.heavy_cost = 0xffffffffu;
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
+        work_next[threadIdx.x] = 0u;     // the next launch's dispensers (stream-ordered after us)
+    general_wave<CULL>(A, env, work, n_chunks, lane);
 }
 
 // ------------------------------------------------------------------ depth 0: whole batches of samples
@@ -2402,10 +2462,13 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves * (kBlock / 64);
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
     if (v.general) {
-        // triangle lights or non-Lambertian materials: the plain general kernel, without chunk feedback
+        // triangle lights, non-Lambertian materials or textures: the general kernel -- persistent waves
+        // (one block per CU is resident), no chunk feedback
         A.fb = ChunkFeedback{};
         A.occlusion = false;
-        const uint32_t ga = grid_for_chunks(n, max_blocks * 2);
+        static const int regen = [] { const char *e = std::getenv("RT_GENERAL_REGEN"); return e ? std::atoi(e) : -1; }();
+        A.regen = regen < 0 ? v.tree.top < 3 : regen != 0;   // < 256 triangles: coherence of a chunk's camera rays buys nothing
+        const uint32_t ga = grid_for_chunks(n, max_blocks);
         if (v.cull) k_path_general<true><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else        k_path_general<false><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
         return;

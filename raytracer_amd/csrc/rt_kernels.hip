@@ -1541,8 +1541,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
         [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
 }
 
-template <bool CULL>
-__global__ __launch_bounds__(kBlock, 1) void k_path_general(const PathArgs A, uint32_t *__restrict__ work,
+// WAVES per SIMD the register allocation aims at: 1 keeps the whole state in registers, 2 spills
+// ~230 of them but hides twice the traversal's load latency -- faster wherever there is a tree to
+// traverse (materials scene 3.8 -> 3.0 ms, area 19.2 -> 11.5), slower with the environment light's
+// table walks in the shading code (demo scene with it 1.11 -> 1.34): launch_path picks.
+template <bool CULL, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_path_general(const PathArgs A, uint32_t *__restrict__ work,
                                                          uint32_t *__restrict__ work_next, int dynamic)
 {
     (void)dynamic;                   // always the dispenser: a wave asks for pixels whenever slots fall free
@@ -2468,9 +2472,12 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         A.occlusion = false;
         static const int regen = [] { const char *e = std::getenv("RT_GENERAL_REGEN"); return e ? std::atoi(e) : -1; }();
         A.regen = regen < 0 ? v.tree.top < 3 : regen != 0;   // < 256 triangles: coherence of a chunk's camera rays buys nothing
-        const uint32_t ga = grid_for_chunks(n, max_blocks);
-        if (v.cull) k_path_general<true><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        else        k_path_general<false><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        static const int forced = [] { const char *e = std::getenv("RT_GENERAL_WAVES"); return e ? std::atoi(e) : 0; }();
+        const int gw = forced ? std::min(2, std::max(1, forced)) : v.env.n ? 1 : 2;
+        const uint32_t ga = grid_for_chunks(n, max_blocks * gw);
+        if (!v.cull)      k_path_general<false, 1><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else if (gw == 1) k_path_general<true, 1><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else              k_path_general<true, 2><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
         return;
     }
     if (v.cull) {

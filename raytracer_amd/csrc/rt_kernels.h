@@ -114,12 +114,16 @@ struct DevView {
     float *first_t;
 };
 
-// One progressive sample of local pixels [p0, p0 + n): the whole path of every pixel
+// Progressive sample(s) of local pixels [p0, p0 + n): the whole path of every pixel
 // (kernel.cu:50-79 -> pathTracer) in ONE launch.  work / work_next: this launch's and the
 // next launch's pair of dispenser counters; fb may be null (no feedback).
+// n_samples > 1: every chunk renders that many consecutive samples (v.cnt, v.cnt + 1, ..) in this one
+// launch -- only where path_renders_runs(v) says so (shallow trees or the scan, no general scene);
+// elsewhere the caller launches once per sample.
 void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                 const ChunkFeedback *fb);
+                 const ChunkFeedback *fb, uint32_t n_samples);
+bool path_renders_runs(const DevView &v);
 constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (two per lane)
 
 // Depth 0 over a deep tree, one batch of n_samples samples of local pixels [p0, p0 + n) in ONE

@@ -550,10 +550,10 @@ __device__ __forceinline__ void fill_hit(const DevView &v, const Ray &r, int32_t
 }
 
 // kernel.cu:65-66,75,77: running mean over progressive samples, alpha = 1.
-__device__ __forceinline__ void finalize_path(const DevView &v, uint32_t p, v3 res)
+__device__ __forceinline__ void finalize_path(const DevView &v, uint32_t p, v3 res, int cnt)
 {
-    float frac1 = 1.0f / v.cnt;
-    float frac2 = frac1 * (v.cnt - 1);
+    float frac1 = 1.0f / cnt;
+    float frac2 = frac1 * (cnt - 1);
     float4 prev = v.fb[p];
     float4 out;
     out.x = frac2 * prev.x + frac1 * res.x;
@@ -605,6 +605,7 @@ struct PathArgs {
     ChunkFeedback fb;
     uint32_t heavy_x4;               // heavy = cost >= heavy_x4 / 4 times the mean chunk cost
     bool regen;                      // general kernel: dead slots take new pixels at once (see general_wave)
+    uint32_t n_samples;              // k_path: progressive samples cnt, cnt + 1, .. a chunk renders in this launch
 };
 // Per-launch values every chunk shares (kept apart from the kernel argument block, which
 // stays read-only in the constant address space).
@@ -702,7 +703,8 @@ struct RayState {
 template <bool CULL, bool COOP, bool DEPTH0>
 __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &env, uint32_t chunk,
                                            uint32_t lane, uint32_t wib,
-                                           unsigned long long *s_best, uint32_t *s_cost, float *st)
+                                           unsigned long long *s_best, uint32_t *s_cost, float *st,
+                                           int cnt, uint32_t &cost_sum)
 {
     using State = RayState<DEPTH0>;
     const DevView &v = A.v;
@@ -776,7 +778,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                     // draws of this bounce: tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
                     S[h].draw += 1u + (ishit[h] ? (uint32_t)L : 0u);
                     if (!ishit[h]) {                         // PathTracer.cu:64 -> return res
-                        if (writer) finalize_path(v, p, S[h].res);
+                        if (writer) finalize_path(v, p, S[h].res, cnt);
                         alive[h] = false;
                     }
                 }
@@ -890,7 +892,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                 done = true;
             }
             if (done) {
-                if (writer) finalize_path(v, p, S[h].res);
+                if (writer) finalize_path(v, p, S[h].res, cnt);
                 alive[h] = false;
             }
             ishit[h] = false;
@@ -914,8 +916,11 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         if (lane == 0) atomicAdd(s_cost, cost);
         __syncthreads();
         cost = *s_cost;
+        cost_sum += cost;
         if (wib != 0)
             return;
+    } else {
+        cost_sum += cost;
     }
 #ifdef RT_TRAV_LOG
     if (lane == 0 && g_log_p0 == A.p0 && chunk < (1u << 17))
@@ -925,9 +930,24 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
         if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
         if (COOP) atomicAdd(&A.ctl->coop_total, 1ull);
-        if (env.feedback)
-            record_cost(A.fb, env, chunk, cost);
     }
+}
+
+// A chunk's run of A.n_samples progressive samples on one wave (or block, COOP): sample cnt + 1 of a
+// pixel starts from the counter and the running mean sample cnt left, both written and read back by
+// the same lane.  Launches over deep trees (feedback, cooperative chunks: other waves of the block
+// read what wave 0 wrote) keep n_samples = 1; shallow ones (C1, C2) render a whole rt_render call in
+// one launch -- no launch gaps and no tail per sample, which is most of a sample's time on a small
+// partition.  The chunk's feedback is recorded once, with the run's summed cost.
+template <bool CULL, bool COOP, bool DEPTH0>
+__device__ __forceinline__ void path_run(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane,
+                                         uint32_t wib, unsigned long long *s_best, uint32_t *s_cost, float *st)
+{
+    uint32_t cost = 0;
+    for (uint32_t s = 0; s < A.n_samples; s++)
+        path_chunk<CULL, COOP, DEPTH0>(A, env, chunk, lane, wib, s_best, s_cost, st, A.v.cnt + (int)s, cost);
+    if (lane == 0 && (!COOP || wib == 0) && env.feedback)
+        record_cost(A.fb, env, chunk, cost);
 }
 
 // ------------------------------------------------------------------ the general path
@@ -1031,7 +1051,7 @@ __device__ __forceinline__ void general_wave(const PathArgs &A, const ChunkEnv &
     v3 ro[2] = {mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)}, rd[2] = {mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)};
     S[0] = GeneralState{}; S[1] = GeneralState{};
     auto end_path = [&](int h) {                             // kernel.cu:75-77, and the stream's position for the next sample
-        finalize_path(v, pl[h], S[h].res);
+        finalize_path(v, pl[h], S[h].res, v.cnt);
         v.rng_ctr[pl[h]] = draw[h];
         alive[h] = false;
     };
@@ -1537,8 +1557,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     run_chunks<CULL>(
         n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t chunk) { path_chunk<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
-        [&](uint32_t chunk) { path_chunk<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+        [&](uint32_t chunk) { path_run<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
+        [&](uint32_t chunk) { path_run<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
 }
 
 // WAVES per SIMD the register allocation aims at: 1 keeps the whole state in registers, 2 spills
@@ -2436,9 +2456,14 @@ static uint32_t grid_for_chunks(uint32_t n, int max_blocks)
     return std::min<uint32_t>(std::max<uint32_t>(g, 1u), (uint32_t)std::max(max_blocks, 1));
 }
 
+bool path_renders_runs(const DevView &v)
+{
+    return !v.general && !(v.cull && v.tree.top >= 3);
+}
+
 void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                 const ChunkFeedback *fb)
+                 const ChunkFeedback *fb, uint32_t n_samples)
 {
     if (n == 0)
         return;
@@ -2449,8 +2474,12 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     A.max_depth = max_depth;
     A.occlusion = v.n_spheres == 0;
     A.ctl = ctl;
-    const int dynamic = v.cull && v.tree.top >= 3;       // >= 256 triangles
-    if (fb) A.fb = *fb;
+    A.n_samples = path_renders_runs(v) ? std::max(n_samples, 1u) : 1u;
+    // (runs keep the strided chunk assignment of shallow scenes: handing chunks out on demand was slower
+    // at every run length, C2 3.53 -> 3.67..4.72 ms)
+    const bool deep = v.cull && v.tree.top >= 3;         // >= 256 triangles
+    const int dynamic = deep;
+    if (fb && deep) A.fb = *fb;
     const bool d0 = max_depth == 0;
     // Waves per SIMD the register allocation aims at.  Depth 0 with culling reaches this kernel
     // only over a shallow tree (deeper ones take the batch pipeline, rt_context.hip): cheap,

@@ -826,6 +826,40 @@ def test_material_parameters_are_required(gpu_ctx_factory):
     assert rc == abi.RT_ERR_INVALID
 
 
+def test_sample_runs_equal_single_samples(gpu_ctx_factory):
+    """Over a shallow tree (C1, C2) and in scan mode one k_path launch renders a run of samples per chunk
+    (path_run): bit-identical to one launch per sample, at depth 0 and with bounces, and the launch count
+    says which happened."""
+    cfg = scenes.c2(160, 90)
+    for depth, cull in [(0, 1), (5, 1), (3, 0)]:
+        a = gpu_ctx_factory(cfg.width, cfg.height)
+        a.upload_scene(cfg.scene)
+        a.set_camera(cfg.camera)
+        a.set_culling(cull)
+        a.reset_stats()
+        a.render(7, depth)                                   # runs of 4 and 3
+        one = a.read_framebuffer()
+        assert a.stats().path_launches == 2 * a.stats().streams
+        a.reset()
+        a.reset_stats()
+        for n in (1, 1, 2, 3):                               # runs of 1, 1, 2, 3
+            a.render(n, depth)
+        assert a.stats().path_launches == 4 * a.stats().streams
+        split = a.read_framebuffer()
+        assert np.array_equal(one["rgba"].view(np.uint32), split["rgba"].view(np.uint32))
+        assert np.array_equal(one["prim_id"], split["prim_id"])
+        ref = orc.render(cfg.scene, cfg.camera, cfg.width, cfg.height, spp=7, max_depth=depth)
+        check_images(one, ref)
+    # a deep tree with bounces keeps one launch per sample (feedback, cooperative chunks)
+    deep = scenes.c3(96, 54, lon=24, lat=24, ground=(8, 4))
+    b = gpu_ctx_factory(deep.width, deep.height)
+    b.upload_scene(deep.scene)
+    b.set_camera(deep.camera)
+    b.reset_stats()
+    b.render(3, 4)
+    assert b.stats().path_launches == 3 * b.stats().streams
+
+
 # ----------------------------------------------------------------------------- mesh textures (N4)
 def test_textured_meshes_full_frames(gpu_ctx_factory):
     """Mesh textures with mip LOD (Model.cu:60-88,304-309, Texture/Texture.cu): the mip chain built on the

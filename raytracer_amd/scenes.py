@@ -177,20 +177,24 @@ def grid_mesh(nx, nz, x0, x1, z0, z1, y, seed=None, amp=0.0):
     return pos.astype(np.float32), nrm.astype(np.float32)
 
 
-def write_obj(path, pos, nrm):
-    """v / vn / f a//a, triangles only: what Mesh::readFile parses (Model.cu:150-206).
-    %.9g round-trips float32 exactly."""
+def write_obj(path, pos, nrm, uv=None):
+    """v / vn / f a//a (with uv: v / vt / vn / f a/a/a), triangles only: what Mesh::readFile parses
+    (Model.cu:150-206).  %.9g round-trips float32 exactly."""
     pos = np.asarray(pos, np.float32).reshape(-1, 3)
     nrm = np.asarray(nrm, np.float32).reshape(-1, 3)
     with open(path, "w") as f:
         f.write("# seeded synthetic mesh (raytracer_amd.scenes)\n")
         for v in pos:
             f.write("v %.9g %.9g %.9g\n" % tuple(v))
+        if uv is not None:
+            for v in np.asarray(uv, np.float32).reshape(-1, 2):
+                f.write("vt %.9g %.9g\n" % tuple(v))
         for v in nrm:
             f.write("vn %.9g %.9g %.9g\n" % tuple(v))
+        sep = "//" if uv is None else "/%d/"
         for i in range(pos.shape[0] // 3):
             a = 3 * i + 1
-            f.write(f"f {a}//{a} {a + 1}//{a + 1} {a + 2}//{a + 2}\n")
+            f.write(" ".join(["f"] + [f"{k}//{k}" if uv is None else f"{k}/{k}/{k}" for k in (a, a + 1, a + 2)]) + "\n")
 
 
 # ----------------------------------------------------------------------------- configs

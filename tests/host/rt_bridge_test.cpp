@@ -45,7 +45,9 @@ struct RtBridge {
                 const std::vector<int> &mesh_first, const std::vector<int> &mesh_count,
                 const std::vector<HostModel> &models,    // triangles, meshes, quadrics: the order
                                                          // initializeScene walks mat_type[] (Scene.cu:143-149)
-                const std::vector<HostQuadric> &quads, const std::vector<HostPointLight> &lights)
+                const std::vector<HostQuadric> &quads, const std::vector<HostPointLight> &lights,
+                // Mesh::initTexture(data, w, h) of the first mesh (Model.cu:315-319) and its triangles' vText
+                const float *tri_uv = nullptr, const float *tex_data = nullptr, int tex_w = 0, int tex_h = 0)
     {
         std::vector<float> pos, nrm, xf, col, qc, lp, li;
         std::vector<int32_t> tmodel, mtype, qtype, mfirst(mesh_first.begin(), mesh_first.end()),
@@ -66,6 +68,13 @@ struct RtBridge {
         d.model_xf = xf.data(); d.model_mat_type = mtype.data(); d.model_color = col.data();
         d.quad_coeff = qc.data(); d.quad_type = qtype.data();
         d.n_point_lights = (int)lights.size(); d.pl_pos = lp.data(); d.pl_illum = li.data();
+        std::vector<int32_t> mesh_tex(mfirst.size(), -1);
+        const int32_t tex_size[2] = {tex_w, tex_h};
+        if (tex_data && !mesh_tex.empty()) {
+            mesh_tex[0] = 0;
+            d.tri_uv = tri_uv; d.n_textures = 1; d.mesh_texture = mesh_tex.data();
+            d.tex_size = tex_size; d.tex_data = tex_data;
+        }
         // DirectionalLight objects (Light.cuh:57) go the same way: d.n_dir_lights, d.dl_dir (the
         // constructor's `direction` argument; the library normalises it as Light.cu:21 does), d.dl_illum
         return rt_upload_scene(ctx, &d) == RT_OK;
@@ -100,10 +109,11 @@ static int die(const RtBridge &b, const char *what)
 
 int main(int argc, char **argv)
 {
-    if (argc != 7) {
-        std::fprintf(stderr, "usage: %s mesh.obj out.pfm width height spp max_depth\n", argv[0]);
+    if (argc != 7 && argc != 9) {
+        std::fprintf(stderr, "usage: %s mesh.obj out.pfm width height spp max_depth [tex_w tex_h]\n", argv[0]);
         return 2;
     }
+    const int tex_w = argc == 9 ? std::atoi(argv[7]) : 0, tex_h = argc == 9 ? std::atoi(argv[8]) : 0;
     const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), spp = std::atoi(argv[5]),
               depth = std::atoi(argv[6]);
 
@@ -120,6 +130,16 @@ int main(int argc, char **argv)
         std::memcpy(tris[i].normal, nrm + 9 * (size_t)i, sizeof(tris[i].normal));
         tris[i].model = 0;                                   // the one Mesh model
     }
+    // with [tex_w tex_h]: the mesh binds a procedural image (what stbi_loadf would hand to initTexture)
+    // and its triangles carry the OBJ's vt coordinates
+    std::vector<float> tri_uv(uv, uv + 6 * (size_t)n), tex;
+    for (int y = 0; y < tex_h; y++)
+        for (int x = 0; x < tex_w; x++) {
+            tex.push_back(((x ^ y) & 1) ? 0.9f : 0.2f);
+            tex.push_back((float)x / (float)tex_w);
+            tex.push_back((float)y / (float)tex_h);
+            tex.push_back(1.0f);
+        }
     rt_obj_free(pos); rt_obj_free(nrm); rt_obj_free(uv);
 
     HostModel mesh{{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, 1 /* LAMBERTIAN */, {0.7f, 0.7f, 0.7f}};
@@ -127,7 +147,8 @@ int main(int argc, char **argv)
                                           {{8.5f, 9.0f, -47.5f}, {300.0f, 350.0f, 450.0f}}};
     RtBridge b;
     if (!b.init(0, W, H)) { std::fprintf(stderr, "rt_bridge_test: rt_create failed: %s\n", rt_last_error(nullptr)); return 1; }
-    if (!b.upload(0, tris, {0}, {n}, {mesh}, {}, lights)) return die(b, "upload");
+    if (!b.upload(0, tris, {0}, {n}, {mesh}, {}, lights, tri_uv.data(), tex.empty() ? nullptr : tex.data(), tex_w, tex_h))
+        return die(b, "upload");
     const float cpos[3] = {0, 0, 0}, look[3] = {0, 0, -1}, up[3] = {0, 1, 0};
     if (!b.camera(cpos, look, 2.0f, 1.0f, 1000.0f, W / 2, H / 2, up)) return die(b, "camera");   // kernel.cu:228-229
     for (int s = 0; s < spp; s++)                            // the frame loop: one more sample per iteration

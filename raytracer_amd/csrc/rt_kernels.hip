@@ -2499,9 +2499,10 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         // (one block per CU is resident), no chunk feedback
         A.fb = ChunkFeedback{};
         A.occlusion = false;
-        static const int regen = [] { const char *e = std::getenv("RT_GENERAL_REGEN"); return e ? std::atoi(e) : -1; }();
+        const char *e_regen = std::getenv("RT_GENERAL_REGEN"), *e_waves = std::getenv("RT_GENERAL_WAVES");   // diagnostics
+        const int regen = e_regen ? std::atoi(e_regen) : -1;
         A.regen = regen < 0 ? v.tree.top < 3 : regen != 0;   // < 256 triangles: coherence of a chunk's camera rays buys nothing
-        static const int forced = [] { const char *e = std::getenv("RT_GENERAL_WAVES"); return e ? std::atoi(e) : 0; }();
+        const int forced = e_waves ? std::atoi(e_waves) : 0;
         const int gw = forced ? std::min(2, std::max(1, forced)) : v.env.n ? 1 : 2;
         const uint32_t ga = grid_for_chunks(n, max_blocks * gw);
         if (!v.cull)      k_path_general<false, 1><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);

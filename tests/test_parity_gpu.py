@@ -860,6 +860,25 @@ def test_sample_runs_equal_single_samples(gpu_ctx_factory):
     assert b.stats().path_launches == 3 * b.stats().streams
 
 
+def test_general_kernel_with_few_persistent_waves(gpu_ctx_factory, monkeypatch):
+    """The general kernel's waves are persistent: with the grid cut to three blocks every wave works through
+    a dozen chunks -- regenerating paths slot by slot over the shallow demo scene (slots straddle chunks,
+    bounce numbers differ within a wave), taking whole chunks over the deeper materials scene -- and the
+    frames still equal the oracle's, ray counts included."""
+    monkeypatch.setenv("RT_MAX_BLOCKS", "3")
+    cases = [(scenes.demo_scene_with_environment(), CameraArgs.for_image(160, 120), 160, 120, 3, 5),
+             (scenes.demo_scene(), CameraArgs.for_image(161, 97), 161, 97, 2, 0),
+             (scenes.material_test_scene()[0],
+              CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0)), 96, 64, 2, 6)]
+    for scene, cam, w, h, spp, depth in cases:
+        got, ref, st = render_both(gpu_ctx_factory, scene, cam, w, h, spp, depth)
+        check_images(got, ref, st)
+    monkeypatch.setenv("RT_GENERAL_WAVES", "1")              # the one-wave build over a tree, too
+    scene, cam, w, h, spp, depth = cases[2]
+    got, ref, st = render_both(gpu_ctx_factory, scene, cam, w, h, spp, depth)
+    check_images(got, ref, st)
+
+
 # ----------------------------------------------------------------------------- mesh textures (N4)
 def test_textured_meshes_full_frames(gpu_ctx_factory):
     """Mesh textures with mip LOD (Model.cu:60-88,304-309, Texture/Texture.cu): the mip chain built on the

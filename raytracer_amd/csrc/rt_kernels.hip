@@ -700,6 +700,14 @@ struct RayState {
 // the reference computes it.
 // COOP: all four waves of the block run the chunk with identical registers and share only
 // the traversals; wave 0 writes.  st: this thread's column of the block's LDS stash.
+// Between the two slots of a lane in the shading code: keeps the scheduler from interleaving them (their
+// live ranges then overlap and the three-wave build spills: 117 -> 14 registers, C2 26.7 -> 29.4 Grays/s;
+// no effect in k_batch, which does not spill, and none on the general kernel's); -DRT_SCHED_FENCE_OFF to compare.
+#ifdef RT_SCHED_FENCE_OFF
+#define RT_SCHED_FENCE() ((void)0)
+#else
+#define RT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <bool CULL, bool COOP, bool DEPTH0>
 __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &env, uint32_t chunk,
                                            uint32_t lane, uint32_t wib,
@@ -792,6 +800,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                     S[h].model = H.model;
                     S[h].wo_y = local_y(H, neg(r.d));        // Object.cu:107-110 on wo = -r.dir
                 }
+                RT_SCHED_FENCE();
             }
         } else {
             // ---- verdict of the shadow rays towards light j: Scene.cu:225-241
@@ -843,6 +852,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                             ss[h] = S[h].thr - m;
                         }
                     }
+                    RT_SCHED_FENCE();
                 }
                 const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
                 if (c0 | c1) {
@@ -896,6 +906,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
                 alive[h] = false;
             }
             ishit[h] = false;
+            RT_SCHED_FENCE();
         }
         const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]);
         if (DEPTH0 || !(a0 | a1))

@@ -2199,8 +2199,10 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
 // from one dispenser per XCD (run_chunks' phase 2: every XCD first works through its own eighth
 // of the range -- a band of the image, hence a part of the tree its L2 can hold -- then helps with
 // the others'), one ticket ahead.
-template <bool CULL>
-__global__ __launch_bounds__(kBlock, 4) void k_batch(const BatchArgs A, uint32_t *__restrict__ work,
+// WAVES per SIMD the register allocation aims at: four (128 VGPRs, 8 spilled) or five (96 VGPRs, ~50
+// spilled, 5 x 30 KB of LDS per CU; six would not fit the LDS).  launch_batch picks, and says why.
+template <bool CULL, int WAVES>
+__global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint32_t *__restrict__ work,
                                                      uint32_t *__restrict__ work_next)
 {
     __shared__ uint32_t s_lds[kFuseRows][kBlock];
@@ -2562,6 +2564,8 @@ static BatchArgs batch_args(const DevView &v, uint32_t p0, uint32_t n, uint32_t 
     return A;
 }
 
+constexpr size_t kLastLevelCacheBytes = 256u << 20;
+
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
                   int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
                   const BatchFeedback *fb)
@@ -2572,8 +2576,18 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
     if (fb) A.fb = *fb;
     const uint32_t px = kPathChunk >> A.ss_log2;
     const uint32_t units = (n + px - 1) / px;
-    const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * 4u);
-    k_batch<true><<<g, kBlock, 0, s>>>(A, work, work_next);   // the batch kernels run with culling only (rt_render)
+    // Five waves per SIMD only over a scene that does not fit the last-level cache (256 MB): there the
+    // traversal waits for HBM and the fifth wave pays (C5 416 -> 390 ms per 16 samples).  Elsewhere it buys
+    // 1.5-2 % (C3 14.1 -> 13.9 ms, C4 57.5 -> 56.6) for 4.6 GB instead of 0.27 GB of HBM traffic per launch
+    // -- its spilled registers' scratch (43 MB over the chip) no longer fits the L2s -- and a small
+    // partition, which is as long as its longest unit, gets slower (an eighth of C3 2.36 -> 2.42 ms).
+    const size_t scene_bytes = ((size_t)v.tree.level_off[v.tree.top] + 1u) * sizeof(NodeGroup) + (size_t)v.n_tris * sizeof(TriRec);
+    const char *e_waves = std::getenv("RT_BATCH_WAVES");                 // diagnostics: force 4 or 5
+    const int waves = e_waves ? (std::atoi(e_waves) >= 5 ? 5 : 4) : scene_bytes > kLastLevelCacheBytes ? 5 : 4;
+    const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves);
+    // the batch kernels run with culling only (rt_render)
+    if (waves == 5) k_batch<true, 5><<<g, kBlock, 0, s>>>(A, work, work_next);
+    else            k_batch<true, 4><<<g, kBlock, 0, s>>>(A, work, work_next);
 }
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,

@@ -970,13 +970,15 @@ def test_environment_light_limits(gpu_ctx_factory):
     assert abi.lib().rt_upload_scene(ctx._h, C.byref(d)) == abi.RT_ERR_INVALID
 
 
-@pytest.mark.parametrize("size", [(8, 8), (40, 24), (130, 70)])
+@pytest.mark.parametrize("size", [(8, 8), (40, 24), (130, 70), (131, 69, 5)])
 def test_batch_kernel_equals_path_kernel_on_odd_shapes(gpu_ctx_factory, monkeypatch, size):
     """k_batch against the per-sample path kernel (RT_BATCH_MIN_TOP keeps a context off k_batch) on
     images and partitions that leave units ragged or lanes without a pixel: tiny frames, 1 / 3 / 8
     ranks, sample counts that end a batch early -- every bit of the three buffers, and the RNG state
     (a second call continues identically)."""
-    w, h = size
+    w, h = size[:2]
+    if len(size) > 2:                                        # the five-wave build (large launches' choice) on a small one
+        monkeypatch.setenv("RT_BATCH_WAVES", str(size[2]))
     cfg = scenes.c3(w, h, f=10, ground=(8, 5))
     monkeypatch.setenv("RT_BATCH_MIN_TOP", "99")
     plain = gpu_ctx_factory(w, h)

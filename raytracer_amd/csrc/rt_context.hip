@@ -555,6 +555,7 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     }
     v.mats = mats;
     v.general = hs.general ? 1 : 0;
+    if (const char *e = std::getenv("RT_FORCE_GENERAL")) v.general = std::atoi(e) != 0 ? 1 : v.general;   // diagnostics
     v.tris = tris; v.tri_pos_of = pos_of; v.tri_cold = cold; v.models = models;
     v.spheres = spheres; v.lights = lights;
     v.n_tris = (int)hs.cold.size();

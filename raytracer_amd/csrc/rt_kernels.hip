@@ -540,6 +540,116 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
     }
 }
 
+// The same query with the traversal PER LANE: every lane walks the tree for its own pair of rays
+// (children still to visit: four bits per level in a 64-bit word; node groups and triangle records
+// through vector loads).  The wave-wide traversal above costs what the UNION of the wave's rays
+// visits -- next to nothing more than one ray for the camera rays of neighbouring pixels or shadow
+// rays towards one light, but most of the tree for the rays a surface scatters: bounce rays (and the
+// shadow rays cast where they land) were 0.3 Grays/s against 18 for the camera rays.  Here a lane pays
+// for its own two rays only (and for its neighbours' divergence).  Same node test, same triangle
+// test, same tie rule (H8) as above, so the same result; children are visited in index order.
+// s_lvl: the tree's level offsets in LDS (a lane indexes them by its own level).
+template <bool CULL, bool LIGHTS = false>
+__device__ __forceinline__ void traverse_lane(const TravArgs &A, const uint32_t *s_lvl, RayPair &r, bool live_x,
+                                              bool live_y, uint32_t &cost)
+{
+    const TreeView &tv = A.tv;
+    uint32_t steps = 0;
+    if (CULL) {
+        int level = tv.top;
+        uint32_t g = 0;
+        unsigned long long pend = 0;
+        auto expand = [&](int lvl, uint32_t grp) -> uint32_t {
+            const float4 *G = (const float4 *)(tv.groups + s_lvl[lvl] + grp);
+            const float4 l0 = G[0], l1 = G[1], l2 = G[2], h0 = G[3], h1 = G[4], h2 = G[5];
+            uint32_t m = 0;
+            bool px, py;
+            float ex, ey;
+            node_test(r, l0.x, l1.x, l2.x, h0.x, h1.x, h2.x, px, py, ex, ey);
+            m |= ((px | py) & !(l0.x > h0.x)) ? 1u : 0u;
+            node_test(r, l0.y, l1.y, l2.y, h0.y, h1.y, h2.y, px, py, ex, ey);
+            m |= ((px | py) & !(l0.y > h0.y)) ? 2u : 0u;
+            node_test(r, l0.z, l1.z, l2.z, h0.z, h1.z, h2.z, px, py, ex, ey);
+            m |= ((px | py) & !(l0.z > h0.z)) ? 4u : 0u;
+            node_test(r, l0.w, l1.w, l2.w, h0.w, h1.w, h2.w, px, py, ex, ey);
+            m |= ((px | py) & !(l0.w > h0.w)) ? 8u : 0u;
+            return m;
+        };
+        bool run = live_x | live_y;
+        if (run)
+            pend = (unsigned long long)expand(level, 0u) << (4 * level);
+        while (run) {
+            const uint32_t m = (uint32_t)(pend >> (4 * level)) & 15u;
+            if (m == 0u) {                       // this group is done: back to its parent's
+                level++;
+                g >>= 2;
+                run = level <= tv.top;
+                continue;
+            }
+            const int j = __builtin_ctz(m);
+            pend &= ~(1ull << (4 * level + j));
+            const uint32_t node = g * kTreeArity + (uint32_t)j;
+            steps++;
+            if (level == 0) {
+                const float4 *tp = (const float4 *)(A.tris + node);
+                const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                TriRec T;
+                T.ax = t0.x; T.ay = t0.y; T.az = t0.z; T.dn = t0.w;
+                T.bx = t1.x; T.by = t1.y; T.bz = t1.z; T.S = t1.w;
+                T.cx = t2.x; T.cy = t2.y; T.cz = t2.z; T.orig = __float_as_int(t2.w);
+                T.nx = t3.x; T.ny = t3.y; T.nz = t3.z; T.qmax = t3.w;
+                tri_test_pair(T, r, live_x, live_y);
+                if (r.best.x < r.stop.x) r.bestp.x = -1.0f;      // occlusion form: the ray is over
+                if (r.best.y < r.stop.y) r.bestp.y = -1.0f;
+            } else {
+                level--;
+                g = node;
+                pend |= (unsigned long long)expand(level, g) << (4 * level);
+            }
+        }
+    } else {
+        for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++) {
+            const TriRec T = load_uniform(&A.tris[node]);
+            tri_test_pair(T, r, live_x, live_y);
+        }
+    }
+    // the wave's cost: its longest lane
+    for (int o = 32; o > 0; o >>= 1)
+        steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
+    cost += steps;
+    if (LIGHTS) {
+        r.tidx = r.idx;
+        r.tidy = r.idy;
+    }
+    // quadrics come last (Scene.cu:31-37), strict < against the triangles' result
+    for (int s = 0; s < A.n_spheres; s++) {
+        const SphereRec S = load_uniform(&A.spheres[s]);
+        float t;
+        if (sphere_hit(S, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
+            r.best.x = t;
+            r.idx = A.n_tris + s;
+        }
+        if (sphere_hit(S, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
+            r.best.y = t;
+            r.idy = A.n_tris + s;
+        }
+    }
+    if (LIGHTS) {                                // triangle lights after every model (Scene.cu:43-58)
+        for (int k = 0; k < A.n_tlights; k++) {
+            const TriRec T = load_uniform(&A.tlights[k].T);
+            float t;
+            if (tri_hit(T, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
+                r.best.x = t;
+                r.idx = T.orig;
+            }
+            if (tri_hit(T, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
+                r.best.y = t;
+                r.idy = T.orig;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ hit record
 __device__ __forceinline__ void fill_hit(const DevView &v, const Ray &r, int32_t id, Hit &h)
 {
@@ -606,6 +716,7 @@ struct PathArgs {
     uint32_t heavy_x4;               // heavy = cost >= heavy_x4 / 4 times the mean chunk cost
     bool regen;                      // general kernel: dead slots take new pixels at once (see general_wave)
     uint32_t n_samples;              // k_path: progressive samples cnt, cnt + 1, .. a chunk renders in this launch
+    bool lane_traversal;             // k_path: bounce rays walk the tree lane by lane (traverse_lane)
 };
 // Per-launch values every chunk shares (kept apart from the kernel argument block, which
 // stays read-only in the constant address space).
@@ -614,6 +725,7 @@ struct ChunkEnv {
     uint32_t heavy_cost;             // cost from which a chunk counts as heavy (feedback)
     uint32_t mean_cost;              // mean chunk cost of the previous launch (0: unknown)
     bool feedback;
+    const uint32_t *s_lvl;           // the tree's level offsets in LDS (traverse_lane), or null
 };
 
 // Feedback of one finished chunk (called by one lane): its class for the next launch.
@@ -762,7 +874,11 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         Stamps sp0;
         // (two copies of the traversal: shadow rays of the occlusion form visit children in index
         // order and keep them as a mask -- cheaper bookkeeping per node group; C2 +1.9 %)
-        if (j >= 0 && A.occlusion)
+        // (and a third: rays a surface scattered, and the shadow rays cast where they land, walk the tree
+        // lane by lane -- see traverse_lane; in the cooperative form every wave then does the same work)
+        if (!DEPTH0 && bounce > 0 && A.lane_traversal)
+            traverse_lane<CULL>(A.T, env.s_lvl, w, j < 0 ? alive[0] : cast[0], j < 0 ? alive[1] : cast[1], cost);
+        else if (j >= 0 && A.occlusion)
             traverse<CULL, COOP, false>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
         else
             traverse<CULL, COOP>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
@@ -1044,9 +1160,13 @@ __device__ __forceinline__ void general_wave(const PathArgs &A, const ChunkEnv &
     };
     const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
     RayPair w;
+    bool scattered = false;          // wave-uniform: no slot of the wave is on its camera ray any more
     auto trace = [&](const v3 o[2], const v3 d[2], const bool live[2]) {
         pair_set(w, o, d, inf2, none2, live, E);
-        traverse<CULL, false, true, true>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp0);
+        if (scattered && A.lane_traversal)       // rays a surface scattered, and what is cast where they land
+            traverse_lane<CULL, true>(A.T, env.s_lvl, w, live[0], live[1], cost);
+        else
+            traverse<CULL, false, true, true>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp0);
     };
     auto ray_of = [&](int h) {
         Ray r;
@@ -1107,6 +1227,7 @@ __device__ __forceinline__ void general_wave(const PathArgs &A, const ChunkEnv &
         }
         if (!(__ballot(alive[0]) | __ballot(alive[1])))
             break;                                           // nothing left to hand out, every path ended
+        scattered = !(__ballot(alive[0] && S[0].bounce == 0) | __ballot(alive[1] && S[1].bounce == 0));
         // ---- closest hit of this bounce: PathTracer.cu:27-64
         trace(ro, rd, alive);
 #pragma unroll
@@ -1561,11 +1682,18 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
     __shared__ unsigned long long s_best[128];
     __shared__ uint32_t s_cost, s_chunk;
     __shared__ float s_stash[2 * RayState<DEPTH0>::kSlots][kBlock];
+    __shared__ uint32_t s_lvl[kMaxLevels];
     float *st = &s_stash[0][threadIdx.x];
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    env.s_lvl = s_lvl;
+    if (!DEPTH0) {
+        if (threadIdx.x < (uint32_t)kMaxLevels)
+            s_lvl[threadIdx.x] = A.T.tv.level_off[threadIdx.x];
+        __syncthreads();
+    }
     run_chunks<CULL>(
         n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
         [&](uint32_t chunk) { path_run<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
@@ -1583,8 +1711,13 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path_general(const PathArgs A
     (void)dynamic;                   // always the dispenser: a wave asks for pixels whenever slots fall free
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_chunks = (A.n + kPathChunk - 1u) / kPathChunk;
+    __shared__ uint32_t s_lvl[kMaxLevels];
+    if (threadIdx.x < (uint32_t)kMaxLevels)
+        s_lvl[threadIdx.x] = A.T.tv.level_off[threadIdx.x];
+    __syncthreads();
     ChunkEnv env{};
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
+    env.s_lvl = s_lvl;
     env.heavy_cost = 0xffffffffu;
     if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
         work_next[threadIdx.x] = 0u;     // the next launch's dispensers (stream-ordered after us)
@@ -2488,6 +2621,10 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     A.occlusion = v.n_spheres == 0;
     A.ctl = ctl;
     A.n_samples = path_renders_runs(v) ? std::max(n_samples, 1u) : 1u;
+    {
+        const char *e = std::getenv("RT_LANE_TRAVERSAL");    // diagnostics: 0 = bounce rays through the wave-wide traversal
+        A.lane_traversal = (e ? std::atoi(e) != 0 : true) && v.cull && v.tree.top >= 3;   // >= 256 triangles
+    }
     // (runs keep the strided chunk assignment of shallow scenes: handing chunks out on demand was slower
     // at every run length, C2 3.53 -> 3.67..4.72 ms)
     const bool deep = v.cull && v.tree.top >= 3;         // >= 256 triangles
@@ -2496,10 +2633,13 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     const bool d0 = max_depth == 0;
     // Waves per SIMD the register allocation aims at.  Depth 0 with culling reaches this kernel
     // only over a shallow tree (deeper ones take the batch pipeline, rt_context.hip): cheap,
-    // uniform chunks, three waves per SIMD measured best (C2: +17 % over two).  With bounces
-    // the per-bounce state wants the registers: two.  The grid is what is resident at once.
+    // uniform chunks, three waves per SIMD measured best (C2: +17 % over two).  With bounces three as
+    // well, spills and all (depth 6: C2 3.89 -> 3.12 ms per sample, C3 6.2 -> 6.0, C4 11.1 -> 10.3;
+    // RT_BOUNCE_WAVES=2 for the two-wave build).  The grid is what is resident at once.
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
-    const int waves = (d0 && v.cull) ? 3 : 2;
+    const char *e_bw = std::getenv("RT_BOUNCE_WAVES");
+    const bool bounce3 = !d0 && v.cull && !(e_bw && std::atoi(e_bw) == 2);
+    const int waves = (d0 && v.cull) || bounce3 ? 3 : 2;
     const uint32_t g = grid_for_chunks(n, max_blocks * waves);
     // Cooperative form from which multiple of the mean chunk cost on: a launch with many
     // chunks per resident wave is throughput-bound, and sharing a chunk among four waves
@@ -2507,6 +2647,9 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // cooperative form shortens (measured on 1/8 partitions of C3 and C4: 2x and 4x best).
     const uint32_t slots = (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves * (kBlock / 64);
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
+    if (A.lane_traversal)
+        A.heavy_x4 *= 2u;            // the cooperative form shares camera and first shadow rays only: later (C3 3.03 -> 2.97 ms, C4 4.54 -> 4.24)
+    if (const char *e = std::getenv("RT_HEAVY_X4")) A.heavy_x4 = (uint32_t)std::max(1, std::atoi(e));   // diagnostics
     if (v.general) {
         // triangle lights, non-Lambertian materials or textures: the general kernel -- persistent waves
         // (one block per CU is resident), no chunk feedback
@@ -2524,7 +2667,8 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         return;
     }
     if (v.cull) {
-        if (!d0) k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        if (bounce3)  k_path<true, false, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        else if (!d0) k_path<true, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else     k_path<true, true, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     } else {
         if (d0) k_path<false, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);

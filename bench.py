@@ -171,6 +171,9 @@ def main():
         ctx.reset()                      # a fresh frame: counters, RNG streams, framebuffer
         ctx.render(spp, 0)
         if world > 1:                    # final framebuffer gathered over xGMI (RCCL)
+            # the previous step's gather (asynchronous, on torch's stream) still reads gather.local: it has had
+            # a whole render to finish, this makes it certain before the buffer is overwritten
+            torch.cuda.current_stream().synchronize()
             if stage is None:
                 ctx.export_local_rgba(gather.local.data_ptr())
             else:

@@ -860,6 +860,37 @@ def test_sample_runs_equal_single_samples(gpu_ctx_factory):
     assert b.stats().path_launches == 3 * b.stats().streams
 
 
+def test_lane_traversal_equals_wave_traversal(gpu_ctx_factory, monkeypatch):
+    """Scattered rays walk the tree lane by lane (traverse_lane) or with the whole wave (traverse): the same
+    node test, triangle test and tie rule either way, so every bit of the frame is the same -- over a soup
+    with exact ties and spheres, through k_path (both builds of the bounce kernel) and through the general
+    kernel (triangle lights, every BRDF)."""
+    soup = soup_scene(np.random.default_rng(33), 1200)
+    cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
+    for scene in (soup, scenes.material_test_scene()[0]):
+        frames = []
+        for knobs in ({"RT_LANE_TRAVERSAL": "0"}, {}, {"RT_BOUNCE_WAVES": "2"}):
+            for k, val in knobs.items():
+                monkeypatch.setenv(k, val)
+            ctx = gpu_ctx_factory(96, 64)
+            ctx.upload_scene(scene)
+            ctx.set_camera(cam)
+            ctx.render(3, 7)
+            frames.append(ctx.read_framebuffer())
+            for k in knobs:
+                monkeypatch.delenv(k)
+        for other in frames[1:]:
+            assert np.array_equal(frames[0]["rgba"].view(np.uint32), other["rgba"].view(np.uint32))
+            assert np.array_equal(frames[0]["prim_id"], other["prim_id"])
+    ref = orc.render(soup, cam, 96, 64, spp=3, max_depth=7)
+    # (frames: of the materials scene; the soup against the oracle once more)
+    ctx = gpu_ctx_factory(96, 64)
+    ctx.upload_scene(soup)
+    ctx.set_camera(cam)
+    ctx.render(3, 7)
+    check_images(ctx.read_framebuffer(), ref)
+
+
 def test_general_kernel_with_few_persistent_waves(gpu_ctx_factory, monkeypatch):
     """The general kernel's waves are persistent: with the grid cut to three blocks every wave works through
     a dozen chunks -- regenerating paths slot by slot over the shallow demo scene (slots straddle chunks,

@@ -2427,8 +2427,12 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const TravArgs T, RayQueue
                                                       float *__restrict__ out_t,
                                                       int32_t *__restrict__ out_id,
                                                       uint32_t *__restrict__ work,
-                                                      uint32_t *__restrict__ work_next, int dynamic)
+                                                      uint32_t *__restrict__ work_next, int dynamic, int lane_mode)
 {
+    __shared__ uint32_t s_lvl[kMaxLevels];
+    if (threadIdx.x < (uint32_t)kMaxLevels)
+        s_lvl[threadIdx.x] = T.tv.level_off[threadIdx.x];
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_chunks = (count + kPathChunk - 1u) / kPathChunk;
     const uint32_t lvloff = T.tv.level_off[lane & (kMaxLevels - 1)];
@@ -2466,7 +2470,33 @@ __global__ __launch_bounds__(kBlock) void k_intersect(const TravArgs T, RayQueue
         uint32_t cost = 0;
         pair_set(w, o, d, inf2, none2, live, T.tv.extent);
         Stamps sp0;
-        traverse<CULL, false, true, true>(T, lvloff, w, lane, 0u, nullptr, cost, sp0);   // triangle lights included (Scene.cu:43-58)
+        // A caller's rays may share an origin or a target (camera rays, shadow rays: the wave-wide walk) or
+        // nothing at all (the per-lane walk, traverse_lane).  lane_mode 2 decides per chunk: the wave's rays
+        // count as coherent when their directions lie within 0.35 of each other per component and their
+        // origins within 1/64 of the culling extent (w.oct bit 3 -- all in one octant -- is not enough:
+        // rays across an octant still visit most of the tree between them).
+        bool per_lane = lane_mode == 1;
+        if (CULL && lane_mode == 2) {
+            float lo[6], hi[6];
+            const float vv[2][6] = {{o[0].x, o[0].y, o[0].z, d[0].x, d[0].y, d[0].z}, {o[1].x, o[1].y, o[1].z, d[1].x, d[1].y, d[1].z}};
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                lo[k] = fminf(live[0] ? vv[0][k] : 3.0e38f, live[1] ? vv[1][k] : 3.0e38f);
+                hi[k] = fmaxf(live[0] ? vv[0][k] : -3.0e38f, live[1] ? vv[1][k] : -3.0e38f);
+                for (int x = 32; x > 0; x >>= 1) {
+                    lo[k] = fminf(lo[k], __shfl_xor(lo[k], x));
+                    hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], x));
+                }
+            }
+            const float eo = T.tv.extent * (1.0f / 64.0f);
+            const bool coherent = (hi[0] - lo[0] <= eo) & (hi[1] - lo[1] <= eo) & (hi[2] - lo[2] <= eo) &
+                                  (hi[3] - lo[3] <= 0.35f) & (hi[4] - lo[4] <= 0.35f) & (hi[5] - lo[5] <= 0.35f);
+            per_lane = !coherent;
+        }
+        if (CULL && per_lane && T.tv.top >= 3)
+            traverse_lane<CULL, true>(T, s_lvl, w, live[0], live[1], cost);
+        else
+            traverse<CULL, false, true, true>(T, lvloff, w, lane, 0u, nullptr, cost, sp0);   // triangle lights included (Scene.cu:43-58)
         if (live[0]) { out_t[i[0]] = w.best.x; out_id[i[0]] = w.idx; }
         if (live[1]) { out_t[i[1]] = w.best.y; out_id[i[1]] = w.idy; }
     }
@@ -2742,8 +2772,10 @@ void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32
         return;
     const int dynamic = v.cull && v.tree.top >= 3;
     const uint32_t g = grid_for_chunks(count, max_blocks * 6);
-    if (v.cull) k_intersect<true><<<g, kBlock, 0, s>>>(trav_args(v), q, count, out_t, out_id, work, work_next, dynamic);
-    else        k_intersect<false><<<g, kBlock, 0, s>>>(trav_args(v), q, count, out_t, out_id, work, work_next, dynamic);
+    const char *e = std::getenv("RT_INTERSECT_LANE");        // diagnostics: 0 wave-wide, 1 per lane, 2 (default) per chunk
+    const int lane_mode = e ? std::atoi(e) : 2;
+    if (v.cull) k_intersect<true><<<g, kBlock, 0, s>>>(trav_args(v), q, count, out_t, out_id, work, work_next, dynamic, lane_mode);
+    else        k_intersect<false><<<g, kBlock, 0, s>>>(trav_args(v), q, count, out_t, out_id, work, work_next, dynamic, lane_mode);
 }
 
 void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,

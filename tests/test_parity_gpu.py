@@ -527,6 +527,28 @@ def test_full_size_c3(gpu_ctx_factory):
         assert np.array_equal(got[key].view(np.uint32), again[key].view(np.uint32)), key
 
 
+def test_full_size_c3_with_bounces(gpu_ctx_factory):
+    """C3 at its full size at the reference's default MAX_DEPTH = 12 (PathTracer.cu:3-5): the bounce kernel
+    with chunk feedback, cooperative chunks and the per-lane traversal of scattered rays over the 69 451-
+    triangle tree, three one-sample launches, against the oracle on windows at the silhouette, on the mesh,
+    on the ground and in the sky."""
+    cfg = scenes.c3()
+    ctx = gpu_ctx_factory(cfg.width, cfg.height)
+    ctx.upload_scene(cfg.scene)
+    ctx.set_camera(cfg.camera)
+    spp, depth = 3, 12
+    ctx.render(spp, depth)
+    got = ctx.read_framebuffer()
+    st = ctx.stats()
+    assert st.bounce_rays > 0 and st.batch_launches == 0
+    hit = got["prim_id"] >= 0
+    ys, xs = np.nonzero(hit[:, :-1] != hit[:, 1:])
+    k = len(xs) // 3
+    crops = [(int(min(max(xs[k] - 6, 0), cfg.width - 12)), int(min(max(ys[k] - 3, 0), cfg.height - 6)), 12, 6),
+             (954, 538, 12, 6), (40, 1040, 12, 6), (900, 4, 12, 3)]
+    _check_crops(got, _oracle_crops(cfg, crops, spp, depth))
+
+
 def test_full_size_c4_rays(gpu_ctx_factory, c4_full):
     """C4's full mesh (871 414 triangles): Scene::hit with the tree equals the scan of every
     triangle, bit for bit, on camera-like and random rays; a handful of them against the oracle."""

@@ -310,6 +310,47 @@ __device__ __forceinline__ void pair_set(RayPair &r, const v3 o[2], const v3 d[2
     r.oct = (oct & 8u) ? oct : 0u;
 }
 
+// What Scene::hit scans after the triangles (Scene.cu:31-64), shared by both traversals: the quadrics, then
+// (LIGHTS) the triangle lights, each with strict < against what stands; before them the closest TRIANGLE
+// is noted -- the mesh whose texture colour the record carries (Model.cu:301-310).
+template <bool LIGHTS>
+__device__ __forceinline__ void after_triangles(const TravArgs &A, RayPair &r)
+{
+    if (LIGHTS) {
+        r.tidx = r.idx;
+        r.tidy = r.idy;
+    }
+    // quadrics come last (Scene.cu:31-37), strict < against the triangles' result
+    for (int s = 0; s < A.n_spheres; s++) {
+        const SphereRec S = load_uniform(&A.spheres[s]);
+        float t;
+        if (sphere_hit(S, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
+            r.best.x = t;
+            r.idx = A.n_tris + s;
+        }
+        if (sphere_hit(S, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
+            r.best.y = t;
+            r.idy = A.n_tris + s;
+        }
+    }
+    // triangle lights after every model (Scene.cu:43-58), strict < again; a hit reports the
+    // light's id n_tris + n_quads + k (what rec.lightidx = k, rec.isLight say in the reference)
+    if (LIGHTS) {
+        for (int k = 0; k < A.n_tlights; k++) {
+            const TriRec T = load_uniform(&A.tlights[k].T);
+            float t;
+            if (tri_hit(T, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
+                r.best.x = t;
+                r.idx = T.orig;
+            }
+            if (tri_hit(T, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
+                r.best.y = t;
+                r.idy = T.orig;
+            }
+        }
+    }
+}
+
 // Scene::hit for the pair in `r` (Scene.cu:8-67): on return r.best / r.idx, r.idy hold the
 // closest accepted t and its reference index per ray (-1 = none; occlusion rays: any hit
 // below r.stop).  `cost` accumulates node groups expanded + triangles tested.
@@ -505,39 +546,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         __syncthreads();
         merge_in();                              // the block's final answer
     }
-    if (LIGHTS) {
-        r.tidx = r.idx;
-        r.tidy = r.idy;
-    }
-    // quadrics come last (Scene.cu:31-37), strict < against the triangles' result
-    for (int s = 0; s < A.n_spheres; s++) {
-        const SphereRec S = load_uniform(&A.spheres[s]);
-        float t;
-        if (sphere_hit(S, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
-            r.best.x = t;
-            r.idx = A.n_tris + s;
-        }
-        if (sphere_hit(S, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
-            r.best.y = t;
-            r.idy = A.n_tris + s;
-        }
-    }
-    // triangle lights after every model (Scene.cu:43-58), strict < again; a hit reports the
-    // light's id n_tris + n_quads + k (what rec.lightidx = k, rec.isLight say in the reference)
-    if (LIGHTS) {
-        for (int k = 0; k < A.n_tlights; k++) {
-            const TriRec T = load_uniform(&A.tlights[k].T);
-            float t;
-            if (tri_hit(T, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
-                r.best.x = t;
-                r.idx = T.orig;
-            }
-            if (tri_hit(T, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
-                r.best.y = t;
-                r.idy = T.orig;
-            }
-        }
-    }
+    after_triangles<LIGHTS>(A, r);
 }
 
 // The same query with the traversal PER LANE: every lane walks the tree for its own pair of rays
@@ -617,37 +626,7 @@ __device__ __forceinline__ void traverse_lane(const TravArgs &A, const uint32_t 
     for (int o = 32; o > 0; o >>= 1)
         steps = max(steps, (uint32_t)__shfl_xor((int)steps, o));
     cost += steps;
-    if (LIGHTS) {
-        r.tidx = r.idx;
-        r.tidy = r.idy;
-    }
-    // quadrics come last (Scene.cu:31-37), strict < against the triangles' result
-    for (int s = 0; s < A.n_spheres; s++) {
-        const SphereRec S = load_uniform(&A.spheres[s]);
-        float t;
-        if (sphere_hit(S, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
-            r.best.x = t;
-            r.idx = A.n_tris + s;
-        }
-        if (sphere_hit(S, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
-            r.best.y = t;
-            r.idy = A.n_tris + s;
-        }
-    }
-    if (LIGHTS) {                                // triangle lights after every model (Scene.cu:43-58)
-        for (int k = 0; k < A.n_tlights; k++) {
-            const TriRec T = load_uniform(&A.tlights[k].T);
-            float t;
-            if (tri_hit(T, mk3(r.ox.x, r.oy.x, r.oz.x), mk3(r.dx.x, r.dy.x, r.dz.x), r.best.x, t)) {
-                r.best.x = t;
-                r.idx = T.orig;
-            }
-            if (tri_hit(T, mk3(r.ox.y, r.oy.y, r.oz.y), mk3(r.dx.y, r.dy.y, r.dz.y), r.best.y, t)) {
-                r.best.y = t;
-                r.idy = T.orig;
-            }
-        }
-    }
+    after_triangles<LIGHTS>(A, r);
 }
 
 // ------------------------------------------------------------------ hit record

@@ -49,11 +49,11 @@ SPH_BYTES = 132.0            # mat4 + inverse + radius
 RAYS_PER_FETCH = 256.0       # one workgroup of 256 rays shares a fetch
 RAY_IO_BYTES = 32.0          # scan model only: 24 B ray in + 8 B (t, id) out per ray
 PIXEL_SAMPLE_BYTES = 52.0    # k_path: fb 16+16, rng counter 4+4, pixmap 4, first id + t 8
-VALU_CYCLES = 4.0            # issue slots a wave64 VALU instruction of this mix takes on its SIMD: with four waves
-                             # per SIMD each busy 24.8 % of its cycles executing VALU (C5, SQ_ACTIVE_INST_VALU over
-                             # SQ_WAVE_CYCLES) the SIMD retires one instruction per 4.3 cycles and no faster
+VALU_MIX = "profiles/r03_valu_mix.json"   # per launch: the kernel's dynamic VALU instruction classes priced with the SIMD
+                             # cycles tools/valu_microbench.hip measured (2 simple / 4 complex or packed / 8 transcendental;
+                             # tools/valu_ceiling.py).  lo / hi: what the counters cannot split priced both ways.
 BATCH_PIXEL_BYTES = 60.0     # k_batch, per pixel and launch: fb 16+16, rng counter 4+4, last draws 4+4, pixmap 4, id + t 8
-PROFILE_ROUNDS = ("r02", "r01")   # committed rocprofv3 summaries under profiles/, newest first
+PROFILE_ROUNDS = ("r03", "r02", "r01")   # committed rocprofv3 summaries under profiles/, newest first
 
 
 def parse():
@@ -106,6 +106,15 @@ def measured_counter(cfg_name, kernel, counter):
         except (OSError, ValueError, IndexError):
             pass
     return None
+
+
+def valu_mix(cfg_name, kernel):
+    """Mix-weighted VALU pipe cycles per launch of `kernel` (tools/valu_ceiling.py), None if absent."""
+    try:
+        with open(os.path.join(ROOT, VALU_MIX)) as f:
+            return json.load(f)[cfg_name][kernel]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def cpu_baseline(cfg, spp, crop_wh):
@@ -270,25 +279,26 @@ def main():
                                 "gbs": scan_gbs, "frac_of_hbm_peak": scan_gbs / HBM_PEAK_GBS,
                                 "pair_tests_per_s": tests / dt if dt else 0.0},
         }
-        # What actually bounds the kernel: VALU issue.  Instructions per launch come from the
-        # committed SQ_INSTS_VALU pass (same command, profiles/), the duration is live; a
-        # wave64 VALU instruction occupies its SIMD for VALU_CYCLES, and the streams' launches
-        # share the chip.
-        valu = measured_counter(cfg.name, kernel, "SQ_INSTS_VALU")
-        if valu and k_ms > 0:
+        # What the kernel is closest to: the VALU pipe.  Per launch, the cycles its instruction mix occupies a SIMD's
+        # VALU for (committed counters x measured per-class cycles, tools/valu_ceiling.py) against the cycles the
+        # launch had on every SIMD; the duration is live, and the streams' launches share the chip.
+        mix = valu_mix(cfg.name, kernel)
+        if mix and k_ms > 0:
             prop = torch.cuda.get_device_properties(dev)
             simds = prop.multi_processor_count * 4
-            clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3
-            if fused:
-                # every stream's launches share the chip: all instructions of the step against its wall time
-                frac = valu * float(launches) / a.steps * VALU_CYCLES / (dt / a.steps * simds * clk_hz)
-                insts = valu
+            clk_hz = float(getattr(prop, "clock_rate", 2400000)) * 1e3      # nominal: the clock under load is lower
+            if fused:   # every stream's launches share the chip: all cycles of the step against its wall time
+                avail = dt / a.steps * simds * clk_hz / (float(launches) / a.steps)
             else:
-                share = max(1, int(st.streams))
-                frac = valu * VALU_CYCLES / (k_ms * 1e-3 * simds * clk_hz / share)
-                insts = valu
-            out["valu_issue"] = {"insts_per_launch": insts, "source": f"profiles/r0x_{cfg.name}_pmc_sq.txt (newest round)",
-                                 "simds": simds, "clock_hz": clk_hz, "frac_of_issue_slots": frac}
+                avail = k_ms * 1e-3 * simds * clk_hz / max(1, int(st.streams))
+            out["valu_issue"] = {"source": VALU_MIX + " (unpacked build's per-class counters, same arithmetic and speed)",
+                                 "valu_insts_per_launch": measured_counter(cfg.name, kernel, "SQ_INSTS_VALU"),
+                                 "pipe_cycles_per_launch_lo": mix["pipe_cycles_lo"], "pipe_cycles_per_launch_hi": mix["pipe_cycles_hi"],
+                                 "simds": simds, "clock_hz": clk_hz,
+                                 "frac_of_valu_pipe_lo": mix["pipe_cycles_lo"] / avail,
+                                 "frac_of_valu_pipe_hi": mix["pipe_cycles_hi"] / avail,
+                                 "note": "mix-weighted with measured prices (2 / 4 / 8 cycles per wave64 instruction), not a flat "
+                                         "4 cycles per instruction; what is left is issue latency of four waves per SIMD (DESIGN.md 5)"}
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (1600, 900),
                                                          "c3": (192, 108), "c4": (32, 18),

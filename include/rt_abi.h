@@ -183,14 +183,18 @@ int rt_scene_hit(rt_context *ctx, int n, const float *org, const float *dir, flo
                  int32_t *prim_id, int32_t *ishit);
 
 /* rt_scene_hit for callers that cannot allocate device memory.  It has no counterpart in the
- * reference; it is for code under HIP graph capture, tight serving loops and harnesses that
- * forbid hipMalloc.  It allocates nothing: org / dir ([n][3]) and t / prim_id / ishit ([n]) are
- * caller-owned DEVICE buffers, and what rt_scene_hit allocates per call (the queue of
- * normalised rays, the kernel's chunk dispensers) lives in a static device array of
- * RT_SCENE_HIT_NOALLOC_MAX_RAYS * 24 + 256 bytes that every GPU the library runs on holds
- * until the process ends.  n above the maximum is refused with RT_ERR_INVALID.  Results are
- * rt_scene_hit's, bit for bit.  All calls on one GPU (from any context) share that GPU's
- * array: calls that overlap on one GPU race.  Blocking, on the context's stream. */
+ * reference; it is for tight serving loops and harnesses that forbid hipMalloc / hipFree.  It
+ * allocates nothing: org / dir ([n][3]) and t / prim_id / ishit ([n]) are caller-owned DEVICE
+ * buffers, and what rt_scene_hit allocates per call (the queue of normalised rays, the kernel's
+ * chunk dispensers) lives in a static device array of RT_SCENE_HIT_NOALLOC_MAX_RAYS * 24 + 256
+ * bytes that every GPU the library runs on holds until the process ends.  n above the maximum is
+ * refused with RT_ERR_INVALID.  Results are rt_scene_hit's, bit for bit.  All calls on one GPU
+ * (from any context) share that GPU's array: calls that overlap on one GPU race.
+ * Ordering: the call launches on the context's own stream and synchronises it before it returns
+ * (blocking, like every call here).  It takes no caller stream or event, so the work that
+ * produces d_org / d_dir must be COMPLETE before the call (synchronise the producing stream
+ * first), and it must not be called while a stream is being captured into a HIP graph: it
+ * synchronises, and its launches are not on the capturing stream. */
 #define RT_SCENE_HIT_NOALLOC_MAX_RAYS 1048576
 int rt_scene_hit_noalloc(rt_context *ctx, int n, const float *d_org, const float *d_dir,
                          float *d_t, int32_t *d_prim_id, int32_t *d_ishit);

@@ -133,7 +133,25 @@ __device__ __forceinline__ bool tri_hit(const TriRec &T, const v3 &o, const v3 &
 // Two rays per lane share every wave-uniform operand; ext_vector float2 arithmetic
 // compiles to v_pk_{mul,add}_f32 (IEEE, no contraction), i.e. the same bits as the
 // scalar code above at half the issue slots.
+#ifndef RT_UNPACKED
 typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+// A/B build (tools/build_variant.sh unpacked -DRT_UNPACKED -fno-slp-vectorize): the same arithmetic as
+// plain fp32 instructions, one per ray.  tools/valu_microbench.hip: a v_pk_*_f32 occupies the SIMD for four
+// cycles like two plain ops, and with packed ops in the stream plain ops no longer issue beside the
+// half-rate ones (v_max / v_min / v_cmp / v_cndmask); without them they do.
+struct f2 { float x, y; };
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2 operator+(f2 a, float b) { return f2{a.x + b, a.y + b}; }
+__device__ __forceinline__ f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
+__device__ __forceinline__ f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
+__device__ __forceinline__ f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#endif
 
 struct RayPair {
     f2 ox, oy, oz, dx, dy, dz;
@@ -180,9 +198,9 @@ __device__ __forceinline__ void node_test(const RayPair &r, float lx, float ly, 
                                           float hy, float hz, bool &px, bool &py, float &ex,
                                           float &ey)
 {
-    f2 ax = __builtin_elementwise_fma(f2{lx, lx}, r.ix, -r.px), bx = __builtin_elementwise_fma(f2{hx, hx}, r.ix, -r.px);
-    f2 ay = __builtin_elementwise_fma(f2{ly, ly}, r.iy, -r.py), by = __builtin_elementwise_fma(f2{hy, hy}, r.iy, -r.py);
-    f2 az = __builtin_elementwise_fma(f2{lz, lz}, r.iz, -r.pz), bz = __builtin_elementwise_fma(f2{hz, hz}, r.iz, -r.pz);
+    f2 ax = f2_fma(f2{lx, lx}, r.ix, -r.px), bx = f2_fma(f2{hx, hx}, r.ix, -r.px);
+    f2 ay = f2_fma(f2{ly, ly}, r.iy, -r.py), by = f2_fma(f2{hy, hy}, r.iy, -r.py);
+    f2 az = f2_fma(f2{lz, lz}, r.iz, -r.pz), bz = f2_fma(f2{hz, hz}, r.iz, -r.pz);
     float tnx = fmaxf(fmaxf(fminf(ax.x, bx.x), fminf(ay.x, by.x)), fmaxf(fminf(az.x, bz.x), 0.0f));
     float tny = fmaxf(fmaxf(fminf(ax.y, bx.y), fminf(ay.y, by.y)), fmaxf(fminf(az.y, bz.y), 0.0f));
     float tfx = fminf(fminf(fmaxf(ax.x, bx.x), fmaxf(ay.x, by.x)), fmaxf(az.x, bz.x));
@@ -205,9 +223,9 @@ __device__ __forceinline__ void node_test_sorted(const RayPair &r, float nx, flo
                                                  float fx, float fy, float fz, bool &px, bool &py,
                                                  float &ex, float &ey)
 {
-    f2 ax = __builtin_elementwise_fma(f2{nx, nx}, r.ix, -r.px), bx = __builtin_elementwise_fma(f2{fx, fx}, r.ix, -r.px);
-    f2 ay = __builtin_elementwise_fma(f2{ny, ny}, r.iy, -r.py), by = __builtin_elementwise_fma(f2{fy, fy}, r.iy, -r.py);
-    f2 az = __builtin_elementwise_fma(f2{nz, nz}, r.iz, -r.pz), bz = __builtin_elementwise_fma(f2{fz, fz}, r.iz, -r.pz);
+    f2 ax = f2_fma(f2{nx, nx}, r.ix, -r.px), bx = f2_fma(f2{fx, fx}, r.ix, -r.px);
+    f2 ay = f2_fma(f2{ny, ny}, r.iy, -r.py), by = f2_fma(f2{fy, fy}, r.iy, -r.py);
+    f2 az = f2_fma(f2{nz, nz}, r.iz, -r.pz), bz = f2_fma(f2{fz, fz}, r.iz, -r.pz);
     float tnx = fmaxf(fmaxf(ax.x, ay.x), fmaxf(az.x, 0.0f));
     float tny = fmaxf(fmaxf(ax.y, ay.y), fmaxf(az.y, 0.0f));
     float tfx = fminf(fminf(bx.x, by.x), bz.x);

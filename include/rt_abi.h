@@ -121,6 +121,7 @@ typedef struct rt_stats {
     uint64_t batch_launches; /* how many of the path_launches were k_batch                           */
     uint64_t batch_listed;   /* units the most recent k_batch launches listed as costly: the next     */
                              /* launch starts with them, one pixel per wave (ordering only)           */
+    uint64_t batch_early;    /* units they listed to go out early, whole, before the bands (ordering only) */
 } rt_stats;
 
 /* Replaces the surface/graph set-up of initCUDA (kernel.cu:193-256): creates the

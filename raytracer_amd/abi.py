@@ -34,7 +34,7 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("bounce_rays", C.c_uint64), ("path_launches", C.c_uint64),
                 ("path_ms", C.c_double), ("render_ms", C.c_double), ("n_prims", C.c_uint64), ("streams", C.c_uint64), ("coop_chunks", C.c_uint64),
-                ("batch_launches", C.c_uint64), ("batch_listed", C.c_uint64)]
+                ("batch_launches", C.c_uint64), ("batch_listed", C.c_uint64), ("batch_early", C.c_uint64)]
 
 
 class RtError(RuntimeError):

@@ -79,6 +79,10 @@ struct Lane {
     uint32_t fb_seq = 0;                 // path launches so far (set rotation)
     // unit-order feedback of k_batch (rt_kernels.h BatchFeedback): three sets rotating by launch
     uint32_t *bheavy[3] = {nullptr, nullptr, nullptr};
+    uint32_t *bearly[3] = {nullptr, nullptr, nullptr};
+    uint32_t *bnorm = nullptr, *blate = nullptr;   // k_classify's lists for the launch at hand (8 x band_units, units)
+    BatchLists *blists = nullptr;
+    uint32_t bfb_shape[3] = {0, 0, 0};              // 1 + ss_log2 of the launch that wrote each set (0: none)
     uint32_t *bflag[3] = {nullptr, nullptr, nullptr};
     FbCounts *bcnt = nullptr;            // [3]
     uint32_t bfb_slots = 0;
@@ -119,6 +123,8 @@ struct rt_context {
     int path_run_wanted = 0;             // samples per k_path launch over shallow trees (RT_PATH_RUN; 0: 4)
     bool feedback_debug = false;
     bool batch_feedback = true;          // costly units of one launch go out first, by pixel, in the next (RT_FEEDBACK=0: off)
+    Knobs knobs;                         // the launchers' diagnostic knobs, read once by rt_create
+    bool force_general = false;          // RT_FORCE_GENERAL=1: every scene through the general kernel (diagnostics)
 
     // stats
     uint64_t samples = 0, primary = 0, launches = 0, timed_launches = 0;
@@ -232,11 +238,17 @@ int alloc_feedback(rt_context *c, Lane &L)
     const size_t units = ((size_t)(&L == &c->lanes[0] ? c->n_local : L.hi - L.lo) + 1) / 2 + 1;
     for (int s = 0; s < 3; s++) {
         if ((rc = dalloc(c, c->part_allocs, L.bheavy[s], units))) return rc;
+        if ((rc = dalloc(c, c->part_allocs, L.bearly[s], units))) return rc;
         if ((rc = dalloc(c, c->part_allocs, L.bflag[s], units))) return rc;
         RT_HIP(c, hipMemset(L.bflag[s], 0, units * sizeof(uint32_t)));
     }
     if ((rc = dalloc(c, c->part_allocs, L.bcnt, 3))) return rc;
     RT_HIP(c, hipMemset(L.bcnt, 0, 3 * sizeof(FbCounts)));
+    // (units of the smallest shape bound every shape's count; a band is rounded up to 64 units)
+    if ((rc = dalloc(c, c->part_allocs, L.bnorm, units + 8 * 64))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, L.blate, units))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, L.blists, 1))) return rc;
+    L.bfb_shape[0] = L.bfb_shape[1] = L.bfb_shape[2] = 0;
     L.bfb_slots = (uint32_t)units;
     L.bfb_seq = 0;
     return RT_OK;
@@ -285,14 +297,10 @@ int do_reset(rt_context *c)
 {
     const size_t n = c->n_local;
     DevView &v = c->v;
-    if (n) {
-        RT_HIP(c, hipMemsetAsync(v.rng_ctr, 0, n * sizeof(uint32_t), c->stream));
-        RT_HIP(c, hipMemsetAsync(v.last_draws, 0, n * sizeof(uint32_t), c->stream));
-        RT_HIP(c, hipMemsetAsync(v.fb, 0, n * sizeof(float4), c->stream));
-        RT_HIP(c, hipMemsetAsync(v.first_t, 0, n * sizeof(float), c->stream));
-        launch_fill_i32(c->stream, v.first_id, n, -1);
-    }
-    RT_HIP(c, hipStreamSynchronize(c->stream));
+    // one launch, stream-ordered before whatever the context's stream does next (rt_render forks its lanes off
+    // this stream): a fresh frame costs no host round trip
+    launch_reset_pixels(c->stream, v, (uint32_t)n);
+    RT_HIP(c, hipGetLastError());
     c->cnt = 0;
     return RT_OK;
 }
@@ -337,12 +345,22 @@ ChunkFeedback next_feedback(Lane &L)
 
 // Feedback sets of k_batch rotate by launch: read what the previous launch wrote, write the next
 // set; the set after that is zeroed here, on the lane's stream, for the launch that will write it.
-int next_batch_feedback(rt_context *c, Lane &L, BatchFeedback &f)
+int next_batch_feedback(rt_context *c, Lane &L, BatchFeedback &f, uint32_t ss_log2)
 {
     const int r = (int)((L.bfb_seq + 2u) % 3u), w = (int)(L.bfb_seq % 3u), z = (int)((L.bfb_seq + 1u) % 3u);
-    f.cnt_r = L.bcnt + r; f.heavy_r = L.bheavy[r]; f.flag_r = L.bflag[r];
-    f.cnt_w = L.bcnt + w; f.heavy_w = L.bheavy[w]; f.flag_w = L.bflag[w];
+    f.cnt_r = L.bcnt + r; f.heavy_r = L.bheavy[r]; f.early_r = L.bearly[r]; f.flag_r = L.bflag[r];
     f.n_slots = L.bfb_slots;
+    f.lists = f.lists_w = L.blists; f.norm = f.norm_w = L.bnorm; f.late = f.late_w = L.blate;
+    if (!c->batch_feedback) {                // ordering off: every unit is ordinary, nothing is recorded
+        f.cnt_w = nullptr; f.heavy_w = nullptr; f.early_w = nullptr; f.flag_w = nullptr;
+        f.flags_valid = 0;
+        return RT_OK;
+    }
+    f.cnt_w = L.bcnt + w; f.heavy_w = L.bheavy[w]; f.early_w = L.bearly[w]; f.flag_w = L.bflag[w];
+    // the lists of set r are for this launch only if a launch of the same shape (samples per wave) wrote them
+    f.flags_valid = L.bfb_shape[r] == ss_log2 + 1u ? 1u : 0u;
+    L.bfb_shape[w] = ss_log2 + 1u;
+    L.bfb_shape[z] = 0;
     RT_HIP(c, hipMemsetAsync(L.bcnt + z, 0, sizeof(FbCounts), L.stream));
     RT_HIP(c, hipMemsetAsync(L.bflag[z], 0, (size_t)L.bfb_slots * sizeof(uint32_t), L.stream));
     L.bfb_seq++;
@@ -361,7 +379,7 @@ void timed_path(rt_context *c, Lane &L, const DevView &v, int max_depth, uint32_
     ChunkFeedback f = next_feedback(L);
     if (e0) (void)hipEventRecord(e0, L.stream);
     launch_path(L.stream, v, L.lo, L.hi - L.lo, max_depth, c->max_blocks, L.ctl,
-                L.ctl->work[L.seq & 1u], L.ctl->work[(L.seq + 1u) & 1u], &f, n_samples);
+                L.ctl->work[L.seq & 1u], L.ctl->work[(L.seq + 1u) & 1u], &f, n_samples, c->knobs);
     L.seq++;
     if (e1) (void)hipEventRecord(e1, L.stream);
     c->launches++;
@@ -435,6 +453,8 @@ extern "C" int rt_create(rt_context **out, int device, int width, int height)
     if (const char *e = std::getenv("RT_BATCH_MIN_TOP")) c->batch_min_top = std::atoi(e);
     if (const char *e = std::getenv("RT_PATH_RUN")) c->path_run_wanted = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("RT_FEEDBACK_DEBUG")) c->feedback_debug = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RT_FORCE_GENERAL")) c->force_general = std::atoi(e) != 0;
+    c->knobs = read_knobs();
     if (rc == RT_OK) rc = setup_partition(c);
     if (rc == RT_OK) rc = do_reset(c);
     if (rc != RT_OK) {
@@ -555,7 +575,7 @@ extern "C" int rt_upload_scene(rt_context *c, const rt_scene_desc *d)
     }
     v.mats = mats;
     v.general = hs.general ? 1 : 0;
-    if (const char *e = std::getenv("RT_FORCE_GENERAL")) v.general = std::atoi(e) != 0 ? 1 : v.general;   // diagnostics
+    if (c->force_general) v.general = 1;                     // diagnostics
     v.tris = tris; v.tri_pos_of = pos_of; v.tri_cold = cold; v.models = models;
     v.spheres = spheres; v.lights = lights;
     v.n_tris = (int)hs.cold.size();
@@ -644,23 +664,35 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
         RT_HIP(c, hipEventRecord(c->ev_r0, s0));
         for (int k = 0; k < nb; k++)
             RT_HIP(c, hipStreamWaitEvent(c->lanes[k].stream, c->ev_r0, 0));
-        for (int done = 0; done < n_samples;) {
+        // A failure inside the loop must not leave the lanes forked behind ev_r0 with the sample count, the
+        // framebuffer's running mean and the lanes' counters out of step: the loop stops BEFORE the failing
+        // batch is counted, the lanes are joined and the stream synchronised below, and then the call fails.
+        int rc_fail = RT_OK;
+        for (int done = 0; done < n_samples && rc_fail == RT_OK;) {
             const uint32_t S = (uint32_t)std::min<int>((int)cap, n_samples - done);
+            // one feedback set per lane, taken before anything of this batch is launched
+            BatchFeedback fbs[8] = {};
+            uint32_t ss_log2 = 0;                            // samples a wave holds: the smallest power of two >= S (<= 64)
+            while (ss_log2 < 6u && (1u << ss_log2) < S) ss_log2++;
+            for (int k = 0; k < nb && rc_fail == RT_OK; k++) {
+                Lane &ln = c->lanes[k];
+                const uint32_t hi = whole ? c->lanes[c->n_lanes - 1].hi : ln.hi;
+                if (hi > ln.lo)
+                    rc_fail = next_batch_feedback(c, ln, fbs[k], ss_log2);
+            }
+            if (rc_fail != RT_OK)
+                break;
             for (int k = 0; k < nb; k++) {
                 Lane &ln = c->lanes[k];
                 const uint32_t lo = ln.lo, hi = whole ? c->lanes[c->n_lanes - 1].hi : ln.hi;
                 if (hi <= lo) continue;
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (c->timing) { e0 = next_event(c); e1 = next_event(c); }
-                BatchFeedback f{};
-                if (c->batch_feedback) {
-                    int rc = next_batch_feedback(c, ln, f);
-                    if (rc) return rc;
-                }
+                const BatchFeedback &f = fbs[k];
                 if (e0) (void)hipEventRecord(e0, ln.stream);
                 launch_batch(ln.stream, c->v, lo, hi - lo, S, c->cnt, c->max_blocks, ln.ctl,
                              ln.ctl->work[ln.seq & 1u], ln.ctl->work[(ln.seq + 1u) & 1u],
-                             c->batch_feedback ? &f : nullptr);
+                             &f, c->knobs);
                 ln.seq++;
                 if (e1) (void)hipEventRecord(e1, ln.stream);
                 c->launches++;
@@ -670,10 +702,20 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             done += (int)S;
             c->samples += (uint64_t)c->n_local * S;
             c->primary += (uint64_t)c->n_local * S;
+            // event pairs are resolved without disturbing the streams: only when the pool would grow past a bound
+            if (c->timing && c->ev_used > 32768) {
+                for (int k = 0; k < nb; k++)
+                    RT_HIP(c, hipStreamSynchronize(c->lanes[k].stream));
+                resolve_events(c);
+            }
         }
         for (int k = 0; k < nb; k++) {
             RT_HIP(c, hipEventRecord(c->lanes[k].done, c->lanes[k].stream));
             RT_HIP(c, hipStreamWaitEvent(s0, c->lanes[k].done, 0));
+        }
+        if (rc_fail != RT_OK) {
+            (void)hipStreamSynchronize(s0);
+            return rc_fail;
         }
     } else {
     c->lanes_used = c->n_lanes;
@@ -721,8 +763,8 @@ extern "C" int rt_render(rt_context *c, int n_samples, int max_depth)
             if (!ln.bcnt || !ln.bfb_seq) continue;
             FbCounts h{};
             RT_HIP(c, hipMemcpy(&h, ln.bcnt + (ln.bfb_seq + 2u) % 3u, sizeof h, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "rt: lane %d launch %u listed %u units, cost total %llu, shape %u\n", k,
-                         ln.bfb_seq, h.n_heavy, (unsigned long long)h.total, h.pad);
+            std::fprintf(stderr, "rt: lane %d launch %u listed %u units, early %u + %u, cost total %llu, shape %u\n", k,
+                         ln.bfb_seq, h.n_heavy, h.n_early_a, h.n_early_b, (unsigned long long)h.total, h.pad);
         }
     }
     float ms = 0.0f;
@@ -824,7 +866,7 @@ extern "C" int rt_scene_hit(rt_context *c, int n, const float *org, const float 
             launch_prepare_rays(s, q, d_org, d_dir, un);
             Lane &L0 = c->lanes[0];
             launch_intersect(s, c->v, q, un, d_t, d_id, c->max_blocks, L0.ctl->work[L0.seq & 1u],
-                             L0.ctl->work[(L0.seq + 1u) & 1u]);
+                             L0.ctl->work[(L0.seq + 1u) & 1u], c->knobs);
             L0.seq++;
             launch_ishit(s, d_t, d_hit, un);
             e = hipStreamSynchronize(s);
@@ -867,7 +909,7 @@ extern "C" int rt_scene_hit_noalloc(rt_context *c, int n, const float *d_org, co
     // the array keeps the last call's contents: the dispensers must start at zero
     RT_HIP(c, hipMemsetAsync(work, 0, kScratchCtlBytes, s));
     launch_prepare_rays(s, q, d_org, d_dir, un);
-    launch_intersect(s, c->v, q, un, d_t, d_prim_id, c->max_blocks, work, work + kWorkSlots);
+    launch_intersect(s, c->v, q, un, d_t, d_prim_id, c->max_blocks, work, work + kWorkSlots, c->knobs);
     launch_ishit(s, d_t, d_ishit, un);
     RT_HIP(c, hipStreamSynchronize(s));
     RT_HIP(c, hipGetLastError());
@@ -923,12 +965,14 @@ extern "C" int rt_get_stats(rt_context *c, rt_stats *st)
     st->coop_chunks = coop_total;
     st->batch_launches = c->batch_launches;
     st->batch_listed = 0;
+    st->batch_early = 0;
     for (int k = 0; k < c->n_lanes; k++) {
         const Lane &ln = c->lanes[k];
         if (!ln.bcnt || !ln.bfb_seq) continue;
         FbCounts h{};
         RT_HIP(c, hipMemcpy(&h, ln.bcnt + (ln.bfb_seq + 2u) % 3u, sizeof h, hipMemcpyDeviceToHost));
         st->batch_listed += std::min(h.n_heavy, ln.bfb_slots);
+        st->batch_early += std::min(h.n_early_a + h.n_early_b, ln.bfb_slots);
     }
     return RT_OK;
 }

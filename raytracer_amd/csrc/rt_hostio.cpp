@@ -47,26 +47,26 @@ extern "C" int rt_obj_load(const char *path, float **pos_out, float **nrm_out, f
     std::ifstream file(path);
     if (!file)                                        // Model.cu:146-148
         return RT_ERR_IO;
-    std::vector<F3> vVertex, vNorm;
-    std::vector<F2> vText;
-    std::vector<std::vector<Idx>> vFace;
+    std::vector<F3> positions, normals;
+    std::vector<F2> texcoords;
+    std::vector<std::vector<Idx>> faces;
     std::string line;
     while (std::getline(file, line)) {                // Model.cu:150-206
         if (line.compare(0, 2, "vt") == 0) {
             std::istringstream s(line.substr(2));
             F2 v{0, 0};
             s >> v.x; s >> v.y;
-            vText.push_back(v);
+            texcoords.push_back(v);
         } else if (line.compare(0, 2, "vn") == 0) {
             std::istringstream s(line.substr(2));
             F3 v{0, 0, 0};
             s >> v.x; s >> v.y; s >> v.z;
-            vNorm.push_back(v);
+            normals.push_back(v);
         } else if (line.compare(0, 1, "v") == 0) {
             std::istringstream s(line.substr(1));
             F3 v{0, 0, 0};
             s >> v.x; s >> v.y; s >> v.z;
-            vVertex.push_back(v);
+            positions.push_back(v);
         } else if (line.compare(0, 1, "f") == 0) {
             std::vector<Idx> face;
             std::istringstream toks(line.substr(1));
@@ -77,13 +77,13 @@ extern "C" int rt_obj_load(const char *path, float **pos_out, float **nrm_out, f
                     return RT_ERR_INVALID;
                 face.push_back(ix);
             }
-            vFace.push_back(face);
+            faces.push_back(face);
         }
     }
-    if (vFace.empty())                                // Model.cu:207-208
+    if (faces.empty())                                // Model.cu:207-208
         return RT_ERR_INVALID;
 
-    const size_t n = vFace.size();
+    const size_t n = faces.size();
     float *pos = (float *)std::malloc(n * 9 * sizeof(float));
     float *nrm = (float *)std::malloc(n * 9 * sizeof(float));
     float *uv = (float *)std::malloc(n * 6 * sizeof(float));
@@ -93,9 +93,9 @@ extern "C" int rt_obj_load(const char *path, float **pos_out, float **nrm_out, f
     }
     std::memset(uv, 0, n * 6 * sizeof(float));
     int status = RT_OK;
-    const bool has_vt = !vText.empty();
+    const bool has_vt = !texcoords.empty();
     for (size_t f = 0; f < n && status == RT_OK; f++) {
-        const auto &face = vFace[f];
+        const auto &face = faces[f];
         // The reference indexes fixed V[3]/N[3]/T[3] arrays by face arity (Model.cu:219-221,
         // 262-263): anything but a triangle is out of bounds there, an error here.
         if (face.size() != 3) { status = RT_ERR_UNSUPPORTED; break; }
@@ -109,15 +109,15 @@ extern "C" int rt_obj_load(const char *path, float **pos_out, float **nrm_out, f
                 in = ix.a;
             }
             // H6: faces must carry normals; the reference reads uninitialised memory otherwise
-            if (iv < 0 || iv >= (int)vVertex.size() || in < 0 || in >= (int)vNorm.size() ||
-                (it >= (int)vText.size())) {
+            if (iv < 0 || iv >= (int)positions.size() || in < 0 || in >= (int)normals.size() ||
+                (it >= (int)texcoords.size())) {
                 status = RT_ERR_INVALID;
                 break;
             }
             float *p = pos + f * 9 + 3 * k, *q = nrm + f * 9 + 3 * k;
-            p[0] = vVertex[iv].x; p[1] = vVertex[iv].y; p[2] = vVertex[iv].z;
-            q[0] = vNorm[in].x; q[1] = vNorm[in].y; q[2] = vNorm[in].z;
-            if (it >= 0) { uv[f * 6 + 2 * k] = vText[it].x; uv[f * 6 + 2 * k + 1] = vText[it].y; }
+            p[0] = positions[iv].x; p[1] = positions[iv].y; p[2] = positions[iv].z;
+            q[0] = normals[in].x; q[1] = normals[in].y; q[2] = normals[in].z;
+            if (it >= 0) { uv[f * 6 + 2 * k] = texcoords[it].x; uv[f * 6 + 2 * k + 1] = texcoords[it].y; }
         }
     }
     if (status != RT_OK) {
@@ -127,7 +127,7 @@ extern "C" int rt_obj_load(const char *path, float **pos_out, float **nrm_out, f
     *pos_out = pos;
     *nrm_out = nrm;
     if (uv_out) *uv_out = uv; else std::free(uv);
-    *n_tris_out = (int32_t)n;                         // Model.cu:282 number = vFace.size()
+    *n_tris_out = (int32_t)n;                         // Model.cu:282 number = faces.size()
     return RT_OK;
 }
 

@@ -7,7 +7,7 @@
 
 namespace rt {
 
-constexpr int kWorkSlots = 12;
+constexpr int kWorkSlots = 24;
 
 // Per-lane control block, resident in device memory.
 struct Ctl {
@@ -21,7 +21,7 @@ struct Ctl {
     unsigned long long coop_total;     // chunks run in the cooperative (four-wave) form since rt_reset_stats
 };
 
-constexpr int kWorkHeavy = 8, kWorkEarly = 9;
+constexpr int kWorkHeavy = 8, kWorkEarly = 9, kWorkLate = 12;   // kWorkLate .. kWorkLate + 7: the late units' slices
 
 // Struct-of-arrays ray queue of rt_scene_hit: lane i of a wave reads element base + i.
 struct RayQueue {
@@ -52,6 +52,13 @@ struct TreeView {
 struct FbCounts {
     uint32_t n_heavy, n_early_a, n_early_b, pad;
     unsigned long long total;            // summed cost of all chunks
+    unsigned long long band[8];          // k_batch: summed cost of the units each XCD's band handed out in band order
+};
+// What k_classify makes of the previous launch's flags, right before a k_batch launch: per band the ordinary units
+// (neither listed, early nor late) as a list, and the late units as one list.
+struct BatchLists {
+    uint32_t n_norm[8];
+    uint32_t n_late, pad[7];
 };
 struct ChunkFeedback {
     const FbCounts *cnt_r;
@@ -75,14 +82,29 @@ struct ChunkFeedback {
 // four waves share what one wave would have carried.  Sets rotate by launch (r: written by the
 // previous launch, w: written now, z: zeroed by the host for the launch after).  Only an ordering
 // hint: every pixel-sample is processed exactly once whatever the sets hold.
+// Costly units below that threshold ("early": >= early_x4 / 4 times the mean unit cost) are handed out whole, right
+// after the listed pixels and before the bands, costliest class first: a launch then ends with cheap units, not with
+// a wave that drew a unit twenty times the mean as its last (longest-processing-time-first).  And the cheapest
+// units (<= late_x16 / 16 of the mean: camera rays that miss everything) are kept back for the very end, after the
+// bands: they touch nothing but the top of the tree, so they lose nothing by leaving band order, and they are the
+// fine-grained work that fills the last stretch, when every wave would otherwise finish a mid-sized unit at its own time.
 struct BatchFeedback {
-    const FbCounts *cnt_r;               // n_heavy, pad = 1 + ss_log2 of the launch that wrote the set, total
-    const uint32_t *heavy_r;             // unit ids
-    const uint32_t *flag_r;              // per unit: != 0 = listed in heavy_r
+    const FbCounts *cnt_r;               // n_heavy, n_early_a / _b, pad = 1 + ss_log2 of the launch that wrote the set, total
+    const uint32_t *heavy_r;             // unit ids: handed out first, one pixel per task
+    const uint32_t *early_r;             // unit ids: handed out next, whole -- class a (costliest) from the front, b from the back
+    const uint32_t *flag_r;              // per unit: 1 = listed in heavy_r, 2 = in early_r, 3 = kept for last (no list: k_classify makes it)
     FbCounts *cnt_w;
     uint32_t *heavy_w;
+    uint32_t *early_w;
     uint32_t *flag_w;
     uint32_t n_slots;                    // entries of the arrays
+    // made by k_classify for THIS launch (launch_batch runs it first, on the same stream)
+    const BatchLists *lists;
+    const uint32_t *norm;                // band y's ordinary units: norm[y * band_units ..], lists->n_norm[y] of them
+    const uint32_t *late;                // lists->n_late units, handed out when every band is used up
+    uint32_t *norm_w, *late_w;           // (the same arrays, for k_classify)
+    BatchLists *lists_w;
+    uint32_t flags_valid;                // 1: flag_r was written by a launch of this shape; 0: every unit is ordinary
 };
 
 struct DevView {
@@ -114,6 +136,28 @@ struct DevView {
     float *first_t;
 };
 
+// Diagnostic knobs of the launchers (A/B measurement only: results never depend on them).  Read from the
+// environment ONCE, by rt_create, and kept in the context: a live context does not change behaviour between
+// launches, and no launch calls getenv.
+struct Knobs {
+    int lane_traversal = 1;      // RT_LANE_TRAVERSAL=0: bounce rays through the wave-wide traversal
+    int bounce_waves = 3;        // RT_BOUNCE_WAVES=2: the two-wave build of the bounce kernel
+    int heavy_x4 = 0;            // RT_HEAVY_X4: cooperative form from this many quarters of the mean chunk cost on (0: chosen per launch)
+    int general_regen = -1;      // RT_GENERAL_REGEN: 0 / 1 force path regeneration of the general kernel off / on
+    int general_waves = 0;       // RT_GENERAL_WAVES: 1 / 2 force the build of the general kernel
+    int units_per_block = 96;    // RT_UNITS_PER_BLOCK: grid sizing of k_batch
+    int batch_waves = 0;         // RT_BATCH_WAVES: 4 / 5 force the build of k_batch
+    int intersect_lane = 2;      // RT_INTERSECT_LANE: 0 wave-wide, 1 per lane, 2 per chunk (rt_scene_hit)
+    int task_prio = 1;           // RT_TASK_PRIO=0: listed pixel tasks of k_batch at ordinary wave priority
+    int early_x4 = 20;           // RT_EARLY_X4: k_batch hands units of >= this many quarters of the mean unit cost out early (0: off;
+                                 // 8 measured 13 % slower on C3 -- too many units out of band order --, 16..48 alike)
+    int grab = 1;                // RT_GRAB: units a wave takes per ticket of a band's dispenser
+    int grab_late = 4;           // RT_GRAB_LATE: ... of the late units' dispenser
+    int late_x16 = 4;            // RT_LATE_X16: k_batch keeps units of <= this many sixteenths of the mean unit cost for last (0: off)
+    int band_help = 1;           // RT_BAND_HELP=0: an XCD that has used its band up helps the others' in fixed cyclic order
+};
+Knobs read_knobs();
+
 // Progressive sample(s) of local pixels [p0, p0 + n): the whole path of every pixel
 // (kernel.cu:50-79 -> pathTracer) in ONE launch.  work / work_next: this launch's and the
 // next launch's pair of dispenser counters; fb may be null (no feedback).
@@ -122,25 +166,30 @@ struct DevView {
 // elsewhere the caller launches once per sample.
 void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                 const ChunkFeedback *fb, uint32_t n_samples);
+                 const ChunkFeedback *fb, uint32_t n_samples, const Knobs &knobs);
 bool path_renders_runs(const DevView &v);
 constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (two per lane)
 
 // Depth 0 over a deep tree, one batch of n_samples samples of local pixels [p0, p0 + n) in ONE
 // kernel: camera rays from predicted counters, the pixels the prediction fails on, shadow rays
 // and the running mean without leaving the wave (k_batch).
+// fb is never null: its lists / norm / late arrays are filled by k_classify inside the launch (norm: 8 bands of
+// batch_band_units(units) entries, late: `units` entries); fb->cnt_w == nullptr switches the feedback off.
+uint32_t batch_band_units(uint32_t units);
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
                   int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                  const BatchFeedback *fb);
+                  const BatchFeedback *fb, const Knobs &knobs);
 
 // Scene::hit on a queue of caller rays (rt_scene_hit).
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,
                       float *out_t, int32_t *out_id, int max_blocks, uint32_t *work,
-                      uint32_t *work_next);
+                      uint32_t *work_next, const Knobs &knobs);
 void launch_scatter_image(hipStream_t s, const uint32_t *pixmap, uint32_t n, const float4 *fb,
                           const int32_t *first_id, const float *first_t, float4 *rgba,
                           int32_t *prim, float *t);
 void launch_fill_i32(hipStream_t s, int32_t *a, size_t n, int32_t value);
+// zero framebuffer, RNG counters, draw counts, t buffer; id buffer = -1 (rt_reset) for local pixels [0, n)
+void launch_reset_pixels(hipStream_t s, const DevView &v, uint32_t n);
 // d_mipmap (Texture.cu:14-45): level dst (dw x dh) of a mip chain from the level above it (sw x sh)
 void launch_mip_level(hipStream_t s, const float4 *src, int sw, int sh, float4 *dst, int dw, int dh);
 void launch_prepare_rays(hipStream_t s, const RayQueue &q, const float *org, const float *dir,

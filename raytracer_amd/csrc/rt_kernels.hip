@@ -107,8 +107,19 @@ extern "C" void rt_debug_log(void *out, unsigned p0, unsigned n)
 // (shader cycles; every stamp costs the wave a scalar-memory round trip, so totals run ~10 % high).
 //  0 wave lifetime   1 dispenser   2 unit prologue (loads until ready)   3 shading between traversals
 //  4 stash save/load 5 traverse    6 node-group load wait   7 node tests + ordering
-//  8 triangle load wait   9 triangle tests   10 unit epilogue   11 units   12 traversals
+//  8 triangle load wait   9 triangle tests   10 unit tail (feedback)   11 units   12 traversals
+// row 1 (segments 16..): 16 prologue loads until arrived   17 ray generation (Philox, camera ray, pair set-up)
+//  18 hit record + BRDF-sample verdict after a camera traversal   19 prediction check / chain walk, records to LDS
+//  20 (phase S) record loads   21 light sampling + shadow pair set-up   22 blocked verdict, radiance
+//  23 epilogue: shares to LDS   24 epilogue: running mean chain + texel store
 __device__ unsigned long long g_stamps[4][16];
+// per wave of the last k_batch launch: begin, end (100 MHz counter), units it took, XCD
+__device__ unsigned long long g_wave_log[8][32768];
+extern "C" void rt_debug_wave_log(unsigned long long *out)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_log), sizeof(unsigned long long) * 8 * 32768);
+}
 extern "C" void rt_debug_stamps(unsigned long long *out, int reset)
 {
     hipDeviceSynchronize();
@@ -119,11 +130,11 @@ extern "C" void rt_debug_stamps(unsigned long long *out, int reset)
     }
 }
 struct Stamps {
-    unsigned long long a[13];
+    unsigned long long a[32];
     unsigned long long last, unit_t0, unit_max, hard_units, hard_passes;
     __device__ __forceinline__ void start()
     {
-        for (int i = 0; i < 13; i++) a[i] = 0;
+        for (int i = 0; i < 32; i++) a[i] = 0;
         unit_max = hard_units = hard_passes = 0;
         last = unit_t0 = __builtin_amdgcn_s_memtime();
     }
@@ -153,6 +164,8 @@ struct Stamps {
         if ((threadIdx.x & 63u) == 0) {
             for (int i = 0; i < 13; i++)
                 if (a[i]) atomicAdd(&g_stamps[kernel][i], a[i]);
+            for (int i = 16; i < 32; i++)
+                if (a[i]) atomicAdd(&g_stamps[1][i - 16], a[i]);
             atomicMax(&g_stamps[kernel][13], unit_max);          // the longest single unit of any wave
             atomicAdd(&g_stamps[kernel][14], hard_units);
             atomicAdd(&g_stamps[kernel][15], hard_passes);
@@ -168,12 +181,14 @@ template <class T> __device__ __forceinline__ void stamp_arrived(const T &v)
     const uint32_t *w = (const uint32_t *)&v;
     asm volatile("" :: "s"(w[0]), "s"(w[sizeof(T) / 4 - 1]));
 }
+__device__ __forceinline__ void stamp_arrived_v(uint32_t v) { asm volatile("" :: "v"(v)); }
 #else
 struct Stamps { };
 #define RT_MARK(sp, seg) do { } while (0)
 #define RT_COUNT(sp, seg) do { } while (0)
 #define RT_STAMP(x)
 template <class T> __device__ __forceinline__ void stamp_arrived(const T &) { }
+__device__ __forceinline__ void stamp_arrived_v(uint32_t) { }
 #endif
 
 constexpr unsigned long long kHeavyFactor = 8;   // heavy = this many times the mean chunk cost (4 and 16 measured slower)
@@ -1710,7 +1725,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path_general(const PathArgs A
 // (Scene.cu:87) + 1 if the BRDF sample is usable (PathTracer.cu:77, the discarded trace of the
 // next iteration).  The shadow rays -- most of the work -- do not feed back into it, and the
 // count itself rarely changes from one sample of a pixel to the next.  So rt_render(n, 0) over a
-// deep tree works in batches of S samples (16 or 32), and a wave takes a UNIT of px pixels x ss
+// deep tree works in batches of S samples (16, 32 or 64), and a wave takes a UNIT of px pixels x ss
 // samples = 128 rays (ss = 2^ss_log2 >= S: 8 x 16, 4 x 32, 2 x 64) through three phases (k_batch,
 // fused_unit below):
 //   P  camera rays of all samples at once from PREDICTED counters: every sample's counter is
@@ -1737,6 +1752,12 @@ struct BatchArgs {
     uint32_t ss_log2;                // log2 of the samples a wave holds (batch_ss_log2)
     int cnt0;                        // samples accumulated before this batch
     bool occlusion;
+    bool task_prio;                  // listed pixel tasks run at raised wave priority (RT_TASK_PRIO=0: off)
+    uint32_t early_x4;               // units of >= early_x4 / 4 times the mean unit cost go out early in the next launch (0: off)
+    uint32_t late_x16;               // units of <= late_x16 / 16 of the mean unit cost are kept for last in the next launch (0: off)
+    uint32_t band_units;             // units per XCD band (a multiple of 64; the last bands may be short or empty)
+    uint32_t grab, grab_late;        // units per ticket: of a band's dispenser, of the late units'
+    bool band_help;                  // a wave out of work helps the band with the most estimated work left (else: cyclic order)
     Ctl *ctl;
     BatchFeedback fb;                // cnt_w == nullptr: no feedback
 };
@@ -1805,7 +1826,7 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
     st[2 * kBlock] = ctr[0]; st[3 * kBlock] = ctr[1];
     st[4 * kBlock] = (live[0] ? 1u : 0u) | (live[1] ? 2u : 0u);
     asm volatile("" ::: "memory");
-    RT_MARK(sp, 3);
+    RT_MARK(sp, 17);
     traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
     asm volatile("" ::: "memory");
     pix[0] = st[0 * kBlock]; pix[1] = st[1 * kBlock];
@@ -1843,6 +1864,7 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
             o.model[h] = H.model;
         }
     }
+    RT_MARK(sp, 18);
 }
 
 // Candidate r of the table: level k = samples before it, of which b hits without and c hits with
@@ -1905,8 +1927,8 @@ __device__ __forceinline__ void write_last(const BatchArgs &A, const PrimaryTrac
 
 template <bool CULL>
 __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                           uint32_t only_px, bool skip_listed, uint32_t heavy_cost,
-                                           uint32_t lane, uint32_t *col, uint32_t *next_counter,
+                                           uint32_t only_px, bool skip_listed, uint32_t heavy_cost, uint32_t early_cost,
+                                           uint32_t late_cost, uint32_t lane, uint32_t *col, uint32_t *next_counter,
                                            uint32_t &ticket, unsigned long long &cost_sum, Stamps &sp)
 {
     // only_px = kAllPixels: the whole unit; else only its pixel `only_px` (a listed unit, split by pixel).
@@ -1939,13 +1961,15 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         const uint32_t last = v.last_draws[p];
         dhat[h] = last ? last : 3u + L;
         col[(h * kRecRows + 7) * kBlock] = 0xffffffffu;     // no record yet: model = -1
+        RT_STAMP(stamp_arrived_v(pix[h]); stamp_arrived_v(base_c[h]); stamp_arrived_v(dhat[h]));
     }
+    RT_MARK(sp, 16);
     const bool listed = skip_listed && A.fb.flag_r[unit] != 0u;
-    // the NEXT unit's ticket: drawn behind the prologue's loads, it comes back while this unit is traced
-    if (lane == 0)
-        ticket = atomicAdd(next_counter, 1u);
-    if (listed)
-        return;                                              // its pixels went out one by one, first
+    if (listed) {                                            // its pixels went out one by one, first
+        if (lane == 0 && next_counter)
+            ticket = atomicAdd(next_counter, 1u);
+        return;
+    }
 
     // Phases P and H share ONE call site of the closest-hit traversal (one copy of its loop in the
     // instruction cache).  mode 0, 1: the two prediction rounds; mode 2: the pixels still open
@@ -2101,6 +2125,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             e_s += e_n;
             e_c = c_new;
         }
+        RT_MARK(sp, 19);
     }
     // every record of the unit is final and in LDS; lanes read their own column from here on
     __builtin_amdgcn_wave_barrier();
@@ -2146,7 +2171,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         S[h].contrib = mk3(0.0f, 0.0f, 0.0f);
         S[h].thr = 0.0f;
     }
-    RT_MARK(sp, 2);
+    RT_MARK(sp, 20);
     RayPair w;
     const uint32_t n_lights = __ballot(hit[0] | hit[1]) ? L : 0u;   // nobody hit: nothing to light
     for (uint32_t j = 0; j < n_lights; j++) {
@@ -2177,7 +2202,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             continue;                                        // nobody casts towards this light
         n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
         pair_set(w, so, sd, sb, st2, cast, E);
-        RT_MARK(sp, 3);
+        RT_MARK(sp, 21);
 #pragma unroll
         for (int h = 0; h < 2; h++) {                        // the record itself stays where it is
             float *t7 = (float *)tmp + h * 7 * kBlock;
@@ -2230,8 +2255,14 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             if (!blocked)                                    // res += ... in light order (Scene.cu:120)
                 S[h].le = add(S[h].le, S[h].contrib);
         }
+        RT_MARK(sp, 22);
     }
-    RT_MARK(sp, 3);
+    // The NEXT unit's ticket: drawn here, it comes back behind the epilogue.  (Drawn at the unit's start, as it used to
+    // be, every wave holds two units when the dispensers run dry -- the one it is in and the one it has a ticket for
+    // -- and the launch's tail is two units long: measured on an eighth of C3, waves ended over 600 us of 2400.)
+    if (lane == 0 && next_counter)
+        ticket = atomicAdd(next_counter, 1u);
+    RT_MARK(sp, 21);
     // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64).  Every sample's share of the
     // running mean px = frac2 * prev + frac1 * c (kernel.cu:65-66,75) goes to LDS: its term
     // frac1 * c, which does not depend on the samples before it, and its frac2.
@@ -2247,6 +2278,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
+    RT_MARK(sp, 23);
     if (px_log2 >= 5u) {
         // few samples per pixel (batches of up to 4): lane q owns pixel q (and q + 64), all channels
 #pragma unroll
@@ -2274,20 +2306,32 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         const uint32_t q = ln & px_mask, ch = ln >> px_log2;
         const uint32_t pl = A.p0 + (unit << px_log2) + q;
         if (ch < 3u && pl < p_end && (only_px == kAllPixels || q == only_px)) {
-            const float *c = (const float *)tmp0 + q + ch * kBlock;
             float prev = prev0.x;
             const uint32_t half = min(A.n_samples, 64u >> px_log2);          // samples held by lanes' first rays
-            for (uint32_t smp = 0; smp < half; smp++, c += 1u << px_log2)
-                prev = c[(3u - ch) * kBlock] * prev + c[0];
-            c = (const float *)tmp0 + q + (4u + ch) * kBlock;
-            for (uint32_t smp = half; smp < A.n_samples; smp++, c += 1u << px_log2)
-                prev = c[(3u - ch) * kBlock] * prev + c[0];
+            const uint32_t stride = 1u << px_log2, fo = (3u - ch) * kBlock;
+            // the chain itself is sequential (every step rounds: kernel.cu:75); its operands are not -- eight
+            // samples' shares are read from LDS at a time, so the chain waits for LDS once per eight steps
+            auto chain = [&](const float *c, uint32_t n) {
+                uint32_t i = 0;
+                for (; i + 8u <= n; i += 8u) {
+                    float t[8], f[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { t[k] = c[0]; f[k] = c[fo]; c += stride; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) prev = f[k] * prev + t[k];
+                }
+                for (; i < n; i++, c += stride)
+                    prev = c[fo] * prev + c[0];
+            };
+            chain((const float *)tmp0 + q + ch * kBlock, half);
+            chain((const float *)tmp0 + q + (4u + ch) * kBlock, A.n_samples - half);
             float *texel = (float *)&v.fb[pl];
             texel[ch] = prev;
             if (ch == 0u)
                 texel[3] = 1.0f;
         }
     }
+    RT_MARK(sp, 24);
     if (lane == 0 && n_shadow)
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
     // feedback for the next launch: what this unit cost, and whether it should go out first, by pixel
@@ -2299,12 +2343,61 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             if (slot < A.fb.n_slots)
                 A.fb.heavy_w[slot] = unit;
         }
+    } else if (A.fb.cnt_w && lane == 0 && (only_px == kAllPixels ? cost : cost << px_log2) >= early_cost) {
+        // costly, but not worth splitting (a pixel task speaks for its unit by its own cost times the unit's pixels:
+        // a unit whose pixels all fall below the re-listing threshold must not drop back into band order): out
+        // early next time, whole (class a: from twice the threshold on)
+        if (atomicExch(&A.fb.flag_w[unit], 2u) == 0u) {
+            const bool a = (only_px == kAllPixels ? cost : cost << px_log2) >= 2u * early_cost;
+            const uint32_t slot = atomicAdd(a ? &A.fb.cnt_w->n_early_a : &A.fb.cnt_w->n_early_b, 1u);
+            if (slot < A.fb.n_slots)                         // (a + b <= units <= n_slots: every unit is listed at most once)
+                A.fb.early_w[a ? slot : A.fb.n_slots - 1u - slot] = unit;
+        }
+    } else if (A.fb.cnt_w && lane == 0 && only_px == kAllPixels && cost <= late_cost) {
+        // next to nothing (its camera rays miss everything): kept for the launch's last stretch next time.  A flag
+        // only -- a third of an image's units are like this, and a list would put every one of them through ONE
+        // counter (measured: 4096 waves on one counter, 460 us per unit instead of 20)
+        A.fb.flag_w[unit] = 3u;
     }
     // the next unit's phase P writes these rows: every lane's reads above must be done first
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     RT_MARK(sp, 10);
     RT_STAMP(sp.unit_end(unit, cost));
+}
+
+// Before every k_batch launch: the previous launch's per-unit flags as lists.  Band y (units [y * band_units,
+// (y + 1) * band_units), band_units a multiple of 64) gets its ordinary units -- flag 0 -- in `norm`, the units kept
+// for last -- flag 3 -- go to `late`; listed and early units have their lists already.  A block takes 2048 units,
+// a wave 64 at a time (one band), and appends with one atomic per wave and class; order inside a list is by
+// arrival, which keeps neighbours together in runs of 64 -- what the bands' locality needs.  k_batch itself
+// cannot build these: a third of an image's units are "late", and a list appended to by every one of them goes
+// through ONE counter (measured: 460 us per unit instead of 20).
+constexpr uint32_t kClassifyPerBlock = 2048;
+__global__ __launch_bounds__(256) void k_classify(const uint32_t *__restrict__ flags, uint32_t flags_valid, uint32_t n_units,
+                                                   uint32_t band_units, uint32_t *__restrict__ norm, uint32_t *__restrict__ late,
+                                                   BatchLists *__restrict__ lists)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t i = 0; i < kClassifyPerBlock / 256u; i++) {
+        const uint32_t u0 = blockIdx.x * kClassifyPerBlock + (i * 4u + wave) * 64u;      // wave-uniform
+        if (u0 >= n_units)
+            break;
+        const uint32_t u = u0 + lane;
+        const uint32_t f = u < n_units ? (flags_valid ? flags[u] : 0u) : 0xffu;
+        const unsigned long long m_n = __ballot(f == 0u), m_l = __ballot(f == 3u);
+        const uint32_t y = u0 / band_units;
+        uint32_t b_n = 0, b_l = 0;
+        if (lane == 0) {
+            if (m_n) b_n = atomicAdd(&lists->n_norm[y], (uint32_t)__popcll(m_n));
+            if (m_l) b_l = atomicAdd(&lists->n_late, (uint32_t)__popcll(m_l));
+        }
+        b_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_n);
+        b_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_l);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (f == 0u) norm[(size_t)y * band_units + b_n + (uint32_t)__popcll(m_n & below)] = u;
+        if (f == 3u) late[b_l + (uint32_t)__popcll(m_l & below)] = u;
+    }
 }
 
 // One kernel per batch and pixel range.  The grid is what is resident at once; waves draw units
@@ -2329,16 +2422,27 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
 #ifdef RT_STAMPS
     sp.start();
     const unsigned long long t_begin = sp.last;
+    unsigned long long t_tasks_end = 0, n_tasks = 0, t_tasks_sum = 0, t_task_max = 0;
+    const unsigned long long w_begin = wall_clock64();       // (s_memtime is per XCD; the 100 MHz counter is the chip's)
+    unsigned long long w_last_start = 0, w_last_unit = 0, w_last_stage = 0, w_last_cost = 0;
 #endif
     const uint32_t px_log2 = 7u - A.ss_log2, px = 1u << px_log2;
     const uint32_t n_units = (A.n + px - 1u) / px;
     // What the previous launch of this shape found costly: those units first, one pixel per task.
-    uint32_t n_listed = 0, heavy_cost = 0xffffffffu;
+    uint32_t n_listed = 0, n_early_a = 0, n_early = 0, heavy_cost = 0xffffffffu, early_cost = 0xffffffffu, late_cost = 0u;
     unsigned long long cost_sum = 0ull;
+    const BatchLists *const LS = A.fb.lists;
+    const bool fb_valid = A.fb.cnt_w && A.fb.flags_valid;    // the lists and flags are the previous launch's, of this shape
     if (A.fb.cnt_w) {
         const FbCounts cr = *A.fb.cnt_r;
-        if (cr.pad == A.ss_log2 + 1u && cr.total) {
+        if (fb_valid && cr.total) {
             n_listed = min(cr.n_heavy, A.fb.n_slots);
+            n_early_a = min(cr.n_early_a, A.fb.n_slots);
+            n_early = n_early_a + min(cr.n_early_b, A.fb.n_slots - n_early_a);
+            late_cost = (uint32_t)std::min<unsigned long long>((unsigned long long)A.late_x16 * cr.total / (16ull * std::max(n_units, 1u)), 0x3fffffffull);
+            if (A.early_x4)                                  // (never below 24 node groups + triangle records)
+                early_cost = (uint32_t)std::min<unsigned long long>(
+                    std::max((unsigned long long)A.early_x4 * cr.total / (4ull * std::max(n_units, 1u)), 24ull), 0x3fffffffull);
             // A unit holds the launch up when it is a good part of what one wave does in the whole
             // launch: listed from a quarter of a resident wave's share on, and never below eight
             // times the mean unit cost (splitting costs lanes) or 96 node groups + triangle records
@@ -2349,31 +2453,111 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         if (blockIdx.x == 0 && threadIdx.x == 0)
             A.fb.cnt_w->pad = A.ss_log2 + 1u;                // (n_heavy and total were zeroed by the host)
     }
-    // Stage -1: the listed units' pixels (one counter for the whole chip); stages 0..7: this XCD's
-    // band of units, then the other XCDs' bands.  One ticket ahead throughout.
-    const uint32_t per = (n_units + 7u) / 8u, xcd = blockIdx.x & 7u;
-    int stage = n_listed ? -1 : 0;
-    uint32_t base = 0, size = 0, ticket = 0;
+    // Stage -2: the listed units' pixels (one counter for the whole chip); stage -1: the early units, whole,
+    // costliest class first; then this XCD's band of ordinary units, then the other XCDs' bands, whichever has the
+    // most work left; last the late units, in eight slices.  The bands' and the late units' lists are k_classify's.
+    // One ticket ahead throughout.
+    const uint32_t per = A.band_units, xcd = blockIdx.x & 7u;
+    const uint32_t n_late = LS->n_late, late_per = (n_late + 7u) / 8u;
+    // stages: -2 listed pixels, -1 early units, 0 this XCD's band, 1 another band, 7 late units, 8 done
+    int stage = n_listed ? -2 : n_early ? -1 : 0;
+    // A ticket of a dispenser stands for `grab` consecutive entries of the stage's list of `nun`; size = its tickets.
+    // (All waves of an XCD draw from one counter, and a counter serves only about nine million draws a second:
+    // 4096 waves on ONE counter took 460 us per sky unit, measured.)
+    uint32_t base = 0, size = 0, nun = 0, grab = 1, ticket = 0, band = xcd, helped = 0, late_helped = 0;
+    const uint32_t *list = nullptr;                          // nullptr: the stage's entries are found otherwise
     uint32_t *ctr = nullptr;
+    // lane y < 8 (and its copies): what a unit of band y cost on average in the previous launch of this shape, x 16 (>= 1)
+    uint32_t band_w = 16u;
+    if (fb_valid) {
+        const uint32_t y = lane & 7u, bsz = LS->n_norm[y];
+        const FbCounts *cr = A.fb.cnt_r;
+        if (cr->total && bsz)
+            band_w = (uint32_t)std::min<unsigned long long>(16ull * cr->band[y] / bsz + 1ull, 0xffffffull);
+    }
+    auto enter_list = [&](uint32_t n, uint32_t g, int slot) {
+        base = 0; nun = n; grab = g; size = (n + g - 1u) / g; ctr = &work[slot]; list = nullptr;
+    };
+    // what the units this wave took from a band cost: added to the band's sum when the wave leaves it (the next
+    // launch's helpers go by these sums)
+    unsigned long long band_cost = 0ull;
+    auto flush_band = [&]() {
+        if (A.fb.cnt_w && lane == 0 && band_cost)
+            atomicAdd(&A.fb.cnt_w->band[band], band_cost);
+        band_cost = 0ull;
+    };
+    auto enter_band = [&](uint32_t y) {
+        flush_band();
+        band = y;
+        base = 0;
+        list = A.fb.norm + (size_t)y * per;
+        nun = (uint32_t)__builtin_amdgcn_readfirstlane((int)LS->n_norm[y]);
+        grab = A.grab;
+        size = (nun + grab - 1u) / grab;
+        ctr = &work[y];
+    };
+    auto enter_late = [&](uint32_t y) {
+        flush_band();
+        base = 0;
+        list = A.fb.late + y * late_per;
+        nun = y * late_per < n_late ? min(late_per, n_late - y * late_per) : 0u;
+        grab = A.grab_late;
+        size = (nun + grab - 1u) / grab;
+        ctr = &work[kWorkLate + y];
+    };
     auto enter = [&](int st) {
-        if (st < 0) {
-            base = 0; size = n_listed << px_log2; ctr = &work[kWorkHeavy];
-        } else {
-            const uint32_t y = (xcd + (uint32_t)st) & 7u;
-            base = y * per;
-            size = base < n_units ? min(per, n_units - base) : 0u;
-            ctr = &work[y];
+        if (st == -2)      enter_list(n_listed << px_log2, 1u, kWorkHeavy);
+        else if (st == -1) enter_list(n_early, 1u, kWorkEarly);
+        else               enter_band(xcd);
+    };
+    // The band with the most work left, by units still to hand out x what its units cost last time (wave-uniform;
+    // -1: every band is used up).  The bands of an image cost very different amounts -- sky against silhouette --,
+    // and helpers that go round in a fixed order reach the costliest band last.
+    auto pick = [&]() -> int {
+        const uint32_t y = lane & 7u;
+        const uint32_t tickets = (LS->n_norm[y] + A.grab - 1u) / A.grab;
+        const uint32_t c = __hip_atomic_load(&work[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t rem = tickets - min(c, tickets);
+        unsigned long long key = rem ? (((unsigned long long)rem * band_w) << 3) | y : 0ull;
+        for (int o = 1; o < 8; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)key, o), hi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), o);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other > key ? other : key;
         }
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)key);
+        const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(key >> 32));
+        return (klo | khi) ? (int)(klo & 7u) : -1;
     };
     enter(stage);
     if (lane == 0 && size)
         ticket = atomicAdd(ctr, 1u);
+    // A listed pixel is the longest dependent chain of the launch (a dozen traversals one after another), and a
+    // launch over a small partition is as long as that chain: its wave issues ahead of the three it shares the SIMD with.
+    if (stage == -2 && A.task_prio)
+        __builtin_amdgcn_s_setprio(3);
     for (;;) {
         uint32_t d = size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) : 0u;
         while (d >= size) {                                  // used up: on to the next stage
-            if (++stage >= 8)
-                break;
-            enter(stage);
+            if (stage == -2)
+                __builtin_amdgcn_s_setprio(0);
+            if (stage < 0) {
+                enter(++stage);
+            } else if (stage == 7) {                          // this slice of the late units is used up: the next
+                if (++late_helped >= 8u) {
+                    stage = 8;
+                    break;
+                }
+                enter_late((xcd + late_helped) & 7u);
+            } else {
+                const int y = A.band_help ? pick() : ++helped < 8u ? (int)((xcd + helped) & 7u) : -1;
+                if (y >= 0) {
+                    stage = 1;
+                    enter_band((uint32_t)y);
+                } else {                                     // every band is used up: what was kept for last
+                    stage = 7;
+                    enter_late(xcd);
+                }
+            }
             d = size;
             if (size) {
                 if (lane == 0)
@@ -2383,20 +2567,71 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         }
         if (stage >= 8)
             break;
-        uint32_t unit = base + d, only_px = kAllPixels;
-        if (stage < 0) {
-            // (a listed id is a unit of this shape: the min only keeps a damaged list harmless --
-            // unit n_units has no pixels)
-            unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.heavy_r[d >> px_log2]), n_units);
-            only_px = d & (px - 1u);
+        const bool in_band = stage == 0 || stage == 1;
+        for (uint32_t k = 0; k < grab; k++) {
+            const uint32_t idx = d * grab + k;
+            if (idx >= nun)
+                break;
+            uint32_t unit, only_px = kAllPixels;
+            if (stage == -2) {
+                // (a listed id is a unit of this shape: the min only keeps a damaged list harmless --
+                // unit n_units has no pixels)
+                unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.heavy_r[idx >> px_log2]), n_units);
+                only_px = idx & (px - 1u);
+            } else if (stage == -1) {
+                const uint32_t slot = idx < n_early_a ? idx : A.fb.n_slots - 1u - (idx - n_early_a);
+                unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.early_r[slot]), n_units);
+            } else {
+                unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)list[base + idx]), n_units);
+            }
+            // the ticket after this one is drawn inside the last unit of this one
+            uint32_t *const next_ctr = (k + 1u == grab || idx + 1u >= nun) ? ctr : nullptr;
+#ifdef RT_STAMPS
+            const unsigned long long t_u0 = __builtin_amdgcn_s_memtime();
+            w_last_start = wall_clock64();
+            w_last_unit = unit; w_last_stage = (unsigned long long)(stage + 2);
+            const unsigned long long cost_before = cost_sum;
+#endif
+            const unsigned long long cost_at = cost_sum;
+            fused_unit<CULL>(A, env, unit, only_px, false, heavy_cost, early_cost, late_cost, lane, col, next_ctr, ticket, cost_sum, sp);
+            if (in_band)
+                band_cost += cost_sum - cost_at;
+#ifdef RT_STAMPS
+            w_last_cost = cost_sum - cost_before;
+            if (stage == -2) {
+                const unsigned long long t_u1 = __builtin_amdgcn_s_memtime();
+                t_tasks_end = wall_clock64();
+                n_tasks++;
+                t_tasks_sum += t_u1 - t_u0;
+                t_task_max = t_u1 - t_u0 > t_task_max ? t_u1 - t_u0 : t_task_max;
+            }
+#endif
         }
-        fused_unit<CULL>(A, env, unit, only_px, stage >= 0 && n_listed != 0u, heavy_cost, lane, col, ctr, ticket, cost_sum, sp);
     }
+    flush_band();
     if (A.fb.cnt_w && lane == 0 && cost_sum)
         atomicAdd(&A.fb.cnt_w->total, cost_sum);
 #ifdef RT_STAMPS
-    sp.a[0] = __builtin_amdgcn_s_memtime() - t_begin;
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    sp.a[0] = t_end - t_begin;
     sp.flush(2);
+    if (lane == 0) {
+        // the launch's timeline: first wave start (as its complement), last listed task's end, last wave's end
+        const uint32_t wid = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+        if (wid < 32768u) {
+            g_wave_log[0][wid] = w_begin;
+            g_wave_log[1][wid] = wall_clock64();
+            g_wave_log[2][wid] = sp.a[11];
+            g_wave_log[3][wid] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (unsigned long long)(blockIdx.x & 7u) << 8 | n_tasks << 16;
+            g_wave_log[4][wid] = w_last_start;
+            g_wave_log[5][wid] = w_last_unit | w_last_stage << 32;
+            g_wave_log[6][wid] = w_last_cost;
+        }
+        atomicMax(&g_stamps[1][12], ~w_begin);
+        atomicMax(&g_stamps[1][14], (unsigned long long)wall_clock64());
+        if (t_tasks_end) atomicMax(&g_stamps[1][13], t_tasks_end);
+        if (n_tasks) { atomicAdd(&g_stamps[1][15], n_tasks); atomicAdd(&g_stamps[1][11], t_tasks_sum); atomicMax(&g_stamps[1][10], t_task_max); }
+    }
 #endif
 }
 
@@ -2494,6 +2729,20 @@ __global__ void k_scatter_image(const uint32_t *__restrict__ pixmap, uint32_t n,
     if (rgba) rgba[pix] = fb[p];
     if (prim) prim[pix] = first_id[p];
     if (t) t[pix] = first_t[p];
+}
+
+// rt_reset: every per-pixel array of the partition in one launch (what re-running initCUDA does, kernel.cu:193-256)
+__global__ void k_reset_pixels(uint32_t *__restrict__ rng_ctr, uint32_t *__restrict__ last_draws, float4 *__restrict__ fb,
+                               int32_t *__restrict__ first_id, float *__restrict__ first_t, uint32_t n)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n)
+        return;
+    rng_ctr[p] = 0u;
+    last_draws[p] = 0u;
+    fb[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    first_id[p] = -1;
+    first_t[p] = 0.0f;
 }
 
 __global__ void k_fill_i32(int32_t *a, size_t n, int32_t value)
@@ -2611,6 +2860,27 @@ static uint32_t grid_for_chunks(uint32_t n, int max_blocks)
     return std::min<uint32_t>(std::max<uint32_t>(g, 1u), (uint32_t)std::max(max_blocks, 1));
 }
 
+Knobs read_knobs()
+{
+    Knobs k;
+    auto geti = [](const char *name, int &dst) { if (const char *e = std::getenv(name)) dst = std::atoi(e); };
+    geti("RT_LANE_TRAVERSAL", k.lane_traversal);
+    geti("RT_BOUNCE_WAVES", k.bounce_waves);
+    geti("RT_HEAVY_X4", k.heavy_x4);
+    geti("RT_GENERAL_REGEN", k.general_regen);
+    geti("RT_GENERAL_WAVES", k.general_waves);
+    geti("RT_UNITS_PER_BLOCK", k.units_per_block);
+    geti("RT_BATCH_WAVES", k.batch_waves);
+    geti("RT_INTERSECT_LANE", k.intersect_lane);
+    geti("RT_TASK_PRIO", k.task_prio);
+    geti("RT_EARLY_X4", k.early_x4);
+    geti("RT_BAND_HELP", k.band_help);
+    geti("RT_LATE_X16", k.late_x16);
+    geti("RT_GRAB", k.grab);
+    geti("RT_GRAB_LATE", k.grab_late);
+    return k;
+}
+
 bool path_renders_runs(const DevView &v)
 {
     return !v.general && !(v.cull && v.tree.top >= 3);
@@ -2618,7 +2888,7 @@ bool path_renders_runs(const DevView &v)
 
 void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                 const ChunkFeedback *fb, uint32_t n_samples)
+                 const ChunkFeedback *fb, uint32_t n_samples, const Knobs &knobs)
 {
     if (n == 0)
         return;
@@ -2630,10 +2900,7 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     A.occlusion = v.n_spheres == 0;
     A.ctl = ctl;
     A.n_samples = path_renders_runs(v) ? std::max(n_samples, 1u) : 1u;
-    {
-        const char *e = std::getenv("RT_LANE_TRAVERSAL");    // diagnostics: 0 = bounce rays through the wave-wide traversal
-        A.lane_traversal = (e ? std::atoi(e) != 0 : true) && v.cull && v.tree.top >= 3;   // >= 256 triangles
-    }
+    A.lane_traversal = knobs.lane_traversal != 0 && v.cull && v.tree.top >= 3;   // >= 256 triangles
     // (runs keep the strided chunk assignment of shallow scenes: handing chunks out on demand was slower
     // at every run length, C2 3.53 -> 3.67..4.72 ms)
     const bool deep = v.cull && v.tree.top >= 3;         // >= 256 triangles
@@ -2646,8 +2913,7 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     // well, spills and all (depth 6: C2 3.89 -> 3.12 ms per sample, C3 6.2 -> 6.0, C4 11.1 -> 10.3;
     // RT_BOUNCE_WAVES=2 for the two-wave build).  The grid is what is resident at once.
     const uint32_t n_chunks = (n + kPathChunk - 1) / kPathChunk;
-    const char *e_bw = std::getenv("RT_BOUNCE_WAVES");
-    const bool bounce3 = !d0 && v.cull && !(e_bw && std::atoi(e_bw) == 2);
+    const bool bounce3 = !d0 && v.cull && knobs.bounce_waves != 2;
     const int waves = (d0 && v.cull) || bounce3 ? 3 : 2;
     const uint32_t g = grid_for_chunks(n, max_blocks * waves);
     // Cooperative form from which multiple of the mean chunk cost on: a launch with many
@@ -2658,16 +2924,15 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
     A.heavy_x4 = n_chunks <= slots ? 8u : n_chunks <= 3u * slots ? 16u : 4u * (uint32_t)kHeavyFactor;
     if (A.lane_traversal)
         A.heavy_x4 *= 2u;            // the cooperative form shares camera and first shadow rays only: later (C3 3.03 -> 2.97 ms, C4 4.54 -> 4.24)
-    if (const char *e = std::getenv("RT_HEAVY_X4")) A.heavy_x4 = (uint32_t)std::max(1, std::atoi(e));   // diagnostics
+    if (knobs.heavy_x4 > 0) A.heavy_x4 = (uint32_t)knobs.heavy_x4;   // diagnostics
     if (v.general) {
         // triangle lights, non-Lambertian materials or textures: the general kernel -- persistent waves
         // (one block per CU is resident), no chunk feedback
         A.fb = ChunkFeedback{};
         A.occlusion = false;
-        const char *e_regen = std::getenv("RT_GENERAL_REGEN"), *e_waves = std::getenv("RT_GENERAL_WAVES");   // diagnostics
-        const int regen = e_regen ? std::atoi(e_regen) : -1;
+        const int regen = knobs.general_regen;
         A.regen = regen < 0 ? v.tree.top < 3 : regen != 0;   // < 256 triangles: coherence of a chunk's camera rays buys nothing
-        const int forced = e_waves ? std::atoi(e_waves) : 0;
+        const int forced = knobs.general_waves;
         const int gw = forced ? std::min(2, std::max(1, forced)) : v.env.n ? 1 : 2;
         const uint32_t ga = grid_for_chunks(n, max_blocks * gw);
         if (!v.cull)      k_path_general<false, 1><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
@@ -2695,13 +2960,16 @@ static uint32_t batch_ss_log2(uint32_t n_samples)
 
 // Blocks of a launch over `units` wave-sized units: at least kUnitsPerBlock / 4 units per wave, at
 // most the resident capacity.  (RT_UNITS_PER_BLOCK overrides, for tuning.)
-static uint32_t batch_grid(uint32_t units, uint32_t cap)
+static uint32_t batch_grid(uint32_t units, uint32_t cap, const Knobs &knobs)
 {
-    static const uint32_t per_block = [] {
-        const char *e = std::getenv("RT_UNITS_PER_BLOCK");
-        return (uint32_t)std::max(1, e ? std::atoi(e) : 96);
-    }();
+    const uint32_t per_block = (uint32_t)std::max(1, knobs.units_per_block);
     return std::min<uint32_t>(std::max<uint32_t>(units / per_block, 1u), cap);
+}
+
+// Units per XCD band: an eighth of the range, rounded up to whole waves of k_classify.
+uint32_t batch_band_units(uint32_t units)
+{
+    return (((units + 7u) / 8u) + 63u) / 64u * 64u;
 }
 
 static BatchArgs batch_args(const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples, int cnt0, Ctl *ctl)
@@ -2721,12 +2989,12 @@ constexpr size_t kLastLevelCacheBytes = 256u << 20;
 
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
                   int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                  const BatchFeedback *fb)
+                  const BatchFeedback *fb, const Knobs &knobs)
 {
     if (n == 0 || n_samples == 0)
         return;
     BatchArgs A = batch_args(v, p0, n, n_samples, cnt0, ctl);
-    if (fb) A.fb = *fb;
+    A.fb = *fb;                                          // (the lists are always there; cnt_w == nullptr: no feedback)
     const uint32_t px = kPathChunk >> A.ss_log2;
     const uint32_t units = (n + px - 1) / px;
     // Five waves per SIMD only over a scene that does not fit the last-level cache (256 MB): there the
@@ -2735,9 +3003,19 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
     // -- its spilled registers' scratch (43 MB over the chip) no longer fits the L2s -- and a small
     // partition, which is as long as its longest unit, gets slower (an eighth of C3 2.36 -> 2.42 ms).
     const size_t scene_bytes = ((size_t)v.tree.level_off[v.tree.top] + 1u) * sizeof(NodeGroup) + (size_t)v.n_tris * sizeof(TriRec);
-    const char *e_waves = std::getenv("RT_BATCH_WAVES");                 // diagnostics: force 4 or 5
-    const int waves = e_waves ? (std::atoi(e_waves) >= 5 ? 5 : 4) : scene_bytes > kLastLevelCacheBytes ? 5 : 4;
-    const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves);
+    const int waves = knobs.batch_waves ? (knobs.batch_waves >= 5 ? 5 : 4) : scene_bytes > kLastLevelCacheBytes ? 5 : 4;
+    const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves, knobs);
+    A.task_prio = knobs.task_prio != 0;
+    A.early_x4 = (uint32_t)std::max(0, knobs.early_x4);
+    A.band_help = knobs.band_help != 0;
+    A.late_x16 = (uint32_t)std::max(0, knobs.late_x16);
+    A.grab = (uint32_t)std::min(64, std::max(1, knobs.grab));
+    A.grab_late = (uint32_t)std::min(64, std::max(1, knobs.grab_late));
+    A.band_units = batch_band_units(units);
+    // the previous launch's flags as this launch's lists (stream-ordered: that launch is over, this one not begun)
+    (void)hipMemsetAsync(A.fb.lists_w, 0, sizeof(BatchLists), s);
+    k_classify<<<(units + kClassifyPerBlock - 1u) / kClassifyPerBlock, 256, 0, s>>>(A.fb.flag_r, A.fb.flags_valid, units, A.band_units,
+                                                                                  A.fb.norm_w, A.fb.late_w, A.fb.lists_w);
     // the batch kernels run with culling only (rt_render)
     if (waves == 5) k_batch<true, 5><<<g, kBlock, 0, s>>>(A, work, work_next);
     else            k_batch<true, 4><<<g, kBlock, 0, s>>>(A, work, work_next);
@@ -2745,14 +3023,13 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
 
 void launch_intersect(hipStream_t s, const DevView &v, const RayQueue &q, uint32_t count,
                       float *out_t, int32_t *out_id, int max_blocks, uint32_t *work,
-                      uint32_t *work_next)
+                      uint32_t *work_next, const Knobs &knobs)
 {
     if (count == 0)
         return;
     const int dynamic = v.cull && v.tree.top >= 3;
     const uint32_t g = grid_for_chunks(count, max_blocks * 6);
-    const char *e = std::getenv("RT_INTERSECT_LANE");        // diagnostics: 0 wave-wide, 1 per lane, 2 (default) per chunk
-    const int lane_mode = e ? std::atoi(e) : 2;
+    const int lane_mode = knobs.intersect_lane;              // diagnostics: 0 wave-wide, 1 per lane, 2 (default) per chunk
     if (v.cull) k_intersect<true><<<g, kBlock, 0, s>>>(trav_args(v), q, count, out_t, out_id, work, work_next, dynamic, lane_mode);
     else        k_intersect<false><<<g, kBlock, 0, s>>>(trav_args(v), q, count, out_t, out_id, work, work_next, dynamic, lane_mode);
 }
@@ -2771,6 +3048,11 @@ void launch_mip_level(hipStream_t s, const float4 *src, int sw, int sh, float4 *
     const float px = (float)(1.0 / (double)(float)dw), py = (float)(1.0 / (double)(float)dh);
     const size_t n = (size_t)dw * dh;
     k_mip_level<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(src, sw, sh, dst, dw, dh, px, py);
+}
+void launch_reset_pixels(hipStream_t s, const DevView &v, uint32_t n)
+{
+    if (n)
+        k_reset_pixels<<<(n + 255) / 256, 256, 0, s>>>(v.rng_ctr, v.last_draws, v.fb, v.first_id, v.first_t, n);
 }
 void launch_fill_i32(hipStream_t s, int32_t *a, size_t n, int32_t value)
 {

@@ -681,9 +681,13 @@ def c5_full():
 def test_full_size_c4_render(gpu_ctx_factory, c4_full):
     """C4 at its full size (871 414 triangles, 3840x2160) through rt_render: k_batch
     over the real tree.  (a) 2 spp against the oracle on windows at
-    the silhouette, on the mesh, the ground and the sky; (b) a 32-sample batch (the shape the
-    bench runs) equals the same 32 samples rendered one call at a time, in every bit of the
-    image, id and t buffers and in the shadow-ray count."""
+    the silhouette, on the mesh, the ground and the sky; (b) 64-sample batches (2 pixels x 64
+    samples per wave: the shape the bench runs) equal the same samples rendered one call at a time,
+    in every bit of the image, id and t buffers and in the shadow-ray count -- three batches in a
+    row, so the third is handed the second's lists (costly units first, by pixel, then the early
+    ones); (c) the first 64-sample batch against the oracle on smaller windows of the same places
+    (22 pixels x 64 samples x up to four scans of 871 k triangles: what the oracle does in half a
+    minute on 16 threads)."""
     cfg = c4_full
     assert cfg.scene.n_tris == 871_414 and (cfg.width, cfg.height) == (3840, 2160)
     ctx = gpu_ctx_factory(cfg.width, cfg.height)
@@ -691,30 +695,42 @@ def test_full_size_c4_render(gpu_ctx_factory, c4_full):
     ctx.set_camera(cfg.camera)
     ctx.render(2, 0)
     got = ctx.read_framebuffer()
-    crops = [_silhouette_window(got, cfg, 8, 4), (1916, 1078, 8, 4), (90, 2084, 8, 4), (1800, 8, 8, 2)]
+    sil = _silhouette_window(got, cfg, 8, 4)
+    crops = [sil, (1916, 1078, 8, 4), (90, 2084, 8, 4), (1800, 8, 8, 2)]
     ref = _check_windows(got, cfg, crops, 2)
     assert 0 < (ref["prim_id"] >= 0).sum() < len(ref["prim_id"])
     assert 0.2 < (got["prim_id"] >= 0).mean() < 1.0
+    small = [(sil[0] + 2, sil[1] + 1, 4, 2), (1918, 1079, 4, 2), (92, 2085, 2, 2), (1803, 8, 2, 1)]
     out, shadow = [], []
     for mode in ("batch", "one by one"):
         ctx.reset()
         ctx.reset_stats()
         if mode == "batch":
-            ctx.render(32, 0)
+            ctx.render(64, 0)
+            first = ctx.read_framebuffer()
+            ctx.render(64, 0)
+            ctx.render(64, 0)
+            st = ctx.stats()
+            assert st.batch_launches == 3 and st.batch_listed + st.batch_early > 0
         else:
-            for _ in range(32):
+            for _ in range(192):
                 ctx.render(1, 0)
         out.append(ctx.read_framebuffer())
         shadow.append(ctx.stats().shadow_rays)
     for k in ("rgba", "t", "prim_id"):
         assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
     assert shadow[0] == shadow[1] and shadow[0] > 0
+    ref = _check_windows(first, cfg, small, 64)
+    assert 0 < (ref["prim_id"] >= 0).sum() < len(ref["prim_id"])
 
 
 def test_full_size_c5_render(gpu_ctx_factory, c5_full):
     """C5 at its full size (10 M triangles, 64 lights, 3840x2160) through rt_render: 1 spp
     against the oracle on a handful of pixels (a hit costs the oracle 65 scans of 10 M
-    triangles), and a 16-sample batch (the bench's shape) against one call per sample."""
+    triangles); a 16-sample batch against one call per sample; and 64-sample batches (the
+    configuration's own sample count: 2 pixels x 64 samples per wave through the five-wave build of
+    k_batch) against one call per sample -- three batches in a row, so the third takes the lists
+    the second wrote."""
     cfg = c5_full
     assert cfg.scene.n_tris == 10_000_000 and cfg.scene.n_lights == 64
     ctx = gpu_ctx_factory(cfg.width, cfg.height)
@@ -730,20 +746,52 @@ def test_full_size_c5_render(gpu_ctx_factory, c5_full):
              (int(xs[far]), int(ys[far]), 2, 1), (int(miss_x[len(miss_x) // 2]), int(miss_y[len(miss_y) // 2]), 2, 1)]
     ref = _check_windows(got, cfg, crops, 1)
     assert (ref["prim_id"] >= 0).sum() >= 6 and ref["shadow"] > 64
-    out, shadow = [], []
-    for mode in ("batch", "one by one"):
-        ctx.reset()
+    for batch, n_batches in ((16, 1), (64, 3)):
+        out, shadow = [], []
+        for mode in ("batch", "one by one"):
+            ctx.reset()
+            ctx.reset_stats()
+            if mode == "batch":
+                for _ in range(n_batches):
+                    ctx.render(batch, 0)
+                st = ctx.stats()
+                assert st.batch_launches == n_batches
+                assert n_batches < 3 or st.batch_listed + st.batch_early > 0
+            else:
+                for _ in range(batch * n_batches):
+                    ctx.render(1, 0)
+            out.append(ctx.read_framebuffer())
+            shadow.append(ctx.stats().shadow_rays)
+        for k in ("rgba", "t", "prim_id"):
+            assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), (batch, k)
+        assert shadow[0] == shadow[1] and shadow[0] > 0
+
+
+def test_five_wave_batch_kernel_against_oracle(gpu_ctx_factory, monkeypatch):
+    """The five-wave build of k_batch (what scenes beyond the last-level cache take: C5) on a small deep
+    scene, forced with RT_BATCH_WAVES=5: whole frames against the oracle at 64 samples per launch, three
+    launches in a row -- the third is handed lists (costly units first, by pixel; early units whole) --
+    and bit-equal to the four-wave build's frames."""
+    cfg = scenes.c3(64, 48, lon=48, lat=40, ground=(10, 6))
+    frames = {}
+    for waves in ("5", "4"):
+        monkeypatch.setenv("RT_BATCH_WAVES", waves)
+        ctx = gpu_ctx_factory(cfg.width, cfg.height)
+        monkeypatch.delenv("RT_BATCH_WAVES")
+        ctx.upload_scene(cfg.scene)
+        ctx.set_camera(cfg.camera)
         ctx.reset_stats()
-        if mode == "batch":
-            ctx.render(16, 0)
-        else:
-            for _ in range(16):
-                ctx.render(1, 0)
-        out.append(ctx.read_framebuffer())
-        shadow.append(ctx.stats().shadow_rays)
+        for _ in range(3):
+            ctx.render(64, 0)
+        st = ctx.stats()
+        assert st.batch_launches == 3
+        frames[waves] = (ctx.read_framebuffer(), st)
+    got, st = frames["5"]
+    assert st.batch_listed + st.batch_early > 0
+    ref = orc.render(cfg.scene, cfg.camera, cfg.width, cfg.height, spp=192, max_depth=0)
+    check_images(got, ref, st)
     for k in ("rgba", "t", "prim_id"):
-        assert np.array_equal(out[0][k].view(np.uint32), out[1][k].view(np.uint32)), k
-    assert shadow[0] == shadow[1] and shadow[0] > 0
+        assert np.array_equal(got[k].view(np.uint32), frames["4"][0][k].view(np.uint32)), k
 
 
 # ----------------------------------------------------------------------------- triangle lights (N3)

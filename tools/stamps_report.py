@@ -13,9 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raytracer_amd import abi, scenes  # noqa: E402
 
-SEG = ["wave lifetime", "dispenser", "unit prologue (loads)", "shading between traversals",
+SEG = ["wave lifetime", "dispenser", "-", "-",
        "stash save/load", "(traverse)", "node-group load wait", "node tests + ordering",
-       "triangle load wait", "triangle tests", "unit epilogue", "units", "traversals"]
+       "triangle load wait", "triangle tests", "unit tail (feedback)", "units", "traversals"]
+SEG1 = ["prologue loads until arrived", "ray generation (Philox, camera ray, pair set-up)",
+        "hit record + BRDF-sample verdict", "prediction check / chain walk, records to LDS",
+        "phase S: record loads", "light sampling + shadow pair set-up", "blocked verdict, radiance",
+        "epilogue: shares to LDS", "epilogue: running-mean chain + texel store"]
 
 
 def main():
@@ -28,9 +32,10 @@ def main():
     with abi.Context(cfg.width, cfg.height, 0) as ctx:
         ctx.upload_scene(cfg.scene)
         ctx.set_camera(cfg.camera)
-        ctx.set_partition(0, world, 64)
-        ctx.render(spp, 0)
-        ctx.reset()
+        ctx.set_partition(int(os.environ.get("STAMPS_RANK", "0")), world, 64)
+        for _ in range(2):                  # two warm-ups: a launch lists costly units with the threshold it takes from
+            ctx.render(spp, 0)              # the launch before it, so the third launch is the first to hand a list out
+            ctx.reset()
         L.rt_debug_stamps(None, 1)
         ctx.render(spp, 0)
         out = (C.c_uint64 * 64)()
@@ -46,15 +51,23 @@ def main():
                       f"{cyc[b] / hist[b]:10.0f} cycles each")
     for k, kname in enumerate(["-", "-", "k_batch", "-"]):
         a = [int(out[16 * k + i]) for i in range(16)]
-        if not a[0]:
+        if not a[0] or k != 2:
             continue
         print(f"== {kname} ({name}, {spp} spp): {a[11]} units, {a[12]} traversals, "
               f"{a[0] / max(a[11], 1):.0f} cycles of wave lifetime per unit")
+        b = [int(out[16 + i]) for i in range(16)]
         for i in range(1, 11):
             if a[i]:
-                print(f"  {SEG[i]:32s} {100.0 * a[i] / a[0]:6.2f} %   {a[i] / max(a[11], 1):10.0f} cycles / unit")
-        print(f"  {'unaccounted':32s} {100.0 * (a[0] - sum(a[1:11])) / a[0]:6.2f} %")
+                print(f"  {SEG[i]:48s} {100.0 * a[i] / a[0]:6.2f} %   {a[i] / max(a[11], 1):10.0f} cycles / unit")
+        for i in range(len(SEG1)):
+            if b[i] and i < 10:
+                print(f"  {SEG1[i]:48s} {100.0 * b[i] / a[0]:6.2f} %   {b[i] / max(a[11], 1):10.0f} cycles / unit")
+        print(f"  {'unaccounted':48s} {100.0 * (a[0] - sum(a[1:11]) - sum(b[:10])) / a[0]:6.2f} %")
         cyc, cost, unit = a[13] >> 32, (a[13] >> 20) & 0xfff, a[13] & 0xfffff
+        t0 = (~b[12]) & 0xffffffffffffffff
+        if b[12]:
+            print(f"  launch timeline (units of 10 ns from the first wave's start): last listed pixel task ends at {b[13] - t0 if b[13] else 0}, "
+                  f"last wave at {b[14] - t0}; {b[15]} listed pixel tasks, mean {b[11] / max(b[15], 1):.0f} cycles, longest {b[10]}")
         print(f"  longest single unit: {cyc} cycles ({cyc / 2.4e3:.0f} us at 2.4 GHz), unit {unit} of its launch, "
               f"{cost} node groups + triangle records; open pixels enumerated: {a[14]}, enumeration passes: {a[15]}")
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ float det_cosf(float x)
 __device__ __forceinline__ Ray camera_ray(const CameraRec &c, float x, float y)
 {
     const float step = 0.25f;
-    float aspect = (float)c.res_x / c.res_y;
+    float aspect = c.aspect;                                           // (float)res_x / res_y (Camera.cu:19), rt_upload.cpp
     v3 dir = add(add(scale(c.front, c.n),
                      scale(scale(scale(c.right, (float)x / c.res_x), step), aspect)),
                  scale(scale(c.up, (float)y / c.res_y), step));
@@ -894,7 +894,7 @@ __device__ __forceinline__ void cam_getxy(const CameraRec &c, v3 poso, float &rx
     rx = 0.0f; ry = 0.0f;
     if (dot(dir, c.front) == 0.0f)
         return;
-    const float aspect = (float)c.res_x / c.res_y;
+    const float aspect = c.aspect;
     const float t = c.n / dot(dir, c.front);
     const v3 rpos = scale(dir, t);
     rx = dot(rpos, c.right) * c.res_x / step / aspect;

@@ -151,6 +151,7 @@ struct Knobs {
     int task_prio = 1;           // RT_TASK_PRIO=0: listed pixel tasks of k_batch at ordinary wave priority
     int early_x4 = 20;           // RT_EARLY_X4: k_batch hands units of >= this many quarters of the mean unit cost out early (0: off;
                                  // 8 measured 13 % slower on C3 -- too many units out of band order --, 16..48 alike)
+    int draw_early = 1;          // RT_DRAW_EARLY=0: the next unit's ticket is always drawn late in the unit
     int grab = 1;                // RT_GRAB: units a wave takes per ticket of a band's dispenser
     int grab_late = 4;           // RT_GRAB_LATE: ... of the late units' dispenser
     int late_x16 = 4;            // RT_LATE_X16: k_batch keeps units of <= this many sixteenths of the mean unit cost for last (0: off)

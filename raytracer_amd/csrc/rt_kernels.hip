@@ -667,6 +667,23 @@ __device__ __forceinline__ void finalize_path(const DevView &v, uint32_t p, v3 r
     v.fb[p] = out;
 }
 
+// (x, y) of global pixel index pix = y * W + x (kernel.cu:46,63-64) without the generic 32-bit division (some
+// thirty-five instructions, twice per camera ray): the quotient from a float estimate, put right by one step either
+// way -- exact for every image whose sides fit 16 bits; anything larger takes the division.
+__device__ __forceinline__ void pixel_xy(uint32_t pix, int width, int height, int &x, int &y)
+{
+    const uint32_t W = (uint32_t)width;
+    if ((uint32_t)(width | height) < 65536u) {
+        uint32_t q = (uint32_t)((float)pix * __builtin_amdgcn_rcpf((float)W));       // within one of pix / W
+        int r = (int)(pix - q * W);
+        if (r < 0) { q -= 1u; r += (int)W; }
+        if (r >= (int)W) { q += 1u; r -= (int)W; }
+        x = r; y = (int)q;
+    } else {
+        x = (int)(pix % W); y = (int)(pix / W);
+    }
+}
+
 // One delta light against one hit: PointLight::lightIllumi (Light/Light.cu:7-14) or
 // DirectionalLight::lightIllumi (Light/Light.cu:21-33), then Scene::evaluateDirectLight up
 // to the shadow-ray test (Scene.cu:212-224).  L is wave-uniform, so the type branch is too.
@@ -849,7 +866,8 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
             float u[4];
             const uint32_t draw = v.rng_ctr[p];
             pixel_uniform4(pix, draw, u);
-            int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
+            int x, y;
+            pixel_xy(pix, v.width, v.height, x, y);
             Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
             ro[h] = r.o; rd[h] = r.d;
             S[h] = State{};
@@ -1206,7 +1224,8 @@ __device__ __forceinline__ void general_wave(const PathArgs &A, const ChunkEnv &
                     draw[h] = v.rng_ctr[p];
                     pixel_uniform4(pix, draw[h], u);         // kernel.cu:67 (H4)
                     draw[h] += 1u;
-                    int x = (int)(pix % (uint32_t)v.width), y = (int)(pix / (uint32_t)v.width);
+                    int x, y;
+            pixel_xy(pix, v.width, v.height, x, y);
                     Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
                     ro[h] = r.o; rd[h] = r.d;
                     S[h] = GeneralState{};
@@ -1756,6 +1775,7 @@ struct BatchArgs {
     uint32_t early_x4;               // units of >= early_x4 / 4 times the mean unit cost go out early in the next launch (0: off)
     uint32_t late_x16;               // units of <= late_x16 / 16 of the mean unit cost are kept for last in the next launch (0: off)
     uint32_t band_units;             // units per XCD band (a multiple of 64; the last bands may be short or empty)
+    bool draw_early_ok;              // the next unit's ticket may be drawn at the unit's start while the dispenser is far from its end
     uint32_t grab, grab_late;        // units per ticket: of a band's dispenser, of the late units'
     bool band_help;                  // a wave out of work helps the band with the most estimated work left (else: cyclic order)
     Ctl *ctl;
@@ -1816,7 +1836,8 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
             // curand_uniform4 of the pixel's own stream
             float u[4];
             pixel_uniform4(pix[h], ctr[h], u);
-            int x = (int)(pix[h] % (uint32_t)v.width), y = (int)(pix[h] / (uint32_t)v.width);
+            int x, y;
+            pixel_xy(pix[h], v.width, v.height, x, y);
             Ray r = camera_ray(v.cam, x - v.width / 2 + u[0], y - v.height / 2 + u[1]);   // kernel.cu:73
             ro[h] = r.o; rd[h] = r.d;
         }
@@ -1928,7 +1949,7 @@ __device__ __forceinline__ void write_last(const BatchArgs &A, const PrimaryTrac
 template <bool CULL>
 __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
                                            uint32_t only_px, bool skip_listed, uint32_t heavy_cost, uint32_t early_cost,
-                                           uint32_t late_cost, uint32_t lane, uint32_t *col, uint32_t *next_counter,
+                                           uint32_t late_cost, bool draw_early, uint32_t lane, uint32_t *col, uint32_t *next_counter,
                                            uint32_t &ticket, unsigned long long &cost_sum, Stamps &sp)
 {
     // only_px = kAllPixels: the whole unit; else only its pixel `only_px` (a listed unit, split by pixel).
@@ -1970,6 +1991,14 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
             ticket = atomicAdd(next_counter, 1u);
         return;
     }
+    // The NEXT unit's ticket.  A draw takes microseconds to come back (the counters live on the memory side), so
+    // while its dispenser still has plenty to hand out a wave draws now, behind the prologue's loads, and has the
+    // answer long before it needs it.  Near the dispenser's end that would leave every wave with two units to do
+    // when it runs dry -- the one it is in and the one it holds a ticket for -- and the launch's tail two units
+    // long (measured on an eighth of C3: waves ended over 600 us of 2400); there the draw waits until just before
+    // the epilogue (below).
+    if (draw_early && lane == 0 && next_counter)
+        ticket = atomicAdd(next_counter, 1u);
 
     // Phases P and H share ONE call site of the closest-hit traversal (one copy of its loop in the
     // instruction cache).  mode 0, 1: the two prediction rounds; mode 2: the pixels still open
@@ -2257,10 +2286,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
         RT_MARK(sp, 22);
     }
-    // The NEXT unit's ticket: drawn here, it comes back behind the epilogue.  (Drawn at the unit's start, as it used to
-    // be, every wave holds two units when the dispensers run dry -- the one it is in and the one it has a ticket for
-    // -- and the launch's tail is two units long: measured on an eighth of C3, waves ended over 600 us of 2400.)
-    if (lane == 0 && next_counter)
+    if (!draw_early && lane == 0 && next_counter)            // the next unit's ticket, late form: back behind the epilogue
         ticket = atomicAdd(next_counter, 1u);
     RT_MARK(sp, 21);
     // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64).  Every sample's share of the
@@ -2422,7 +2448,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
 #ifdef RT_STAMPS
     sp.start();
     const unsigned long long t_begin = sp.last;
-    unsigned long long t_tasks_end = 0, n_tasks = 0, t_tasks_sum = 0, t_task_max = 0;
+    unsigned long long t_tasks_end = 0, n_tasks_done = 0, t_tasks_sum = 0, t_task_max = 0;
     const unsigned long long w_begin = wall_clock64();       // (s_memtime is per XCD; the 100 MHz counter is the chip's)
     unsigned long long w_last_start = 0, w_last_unit = 0, w_last_stage = 0, w_last_cost = 0;
 #endif
@@ -2459,11 +2485,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
     // One ticket ahead throughout.
     const uint32_t per = A.band_units, xcd = blockIdx.x & 7u;
     const uint32_t n_late = LS->n_late, late_per = (n_late + 7u) / 8u;
-    // stages: -2 listed pixels, -1 early units, 0 this XCD's band, 1 another band, 7 late units, 8 done
-    int stage = n_listed ? -2 : n_early ? -1 : 0;
-    // A ticket of a dispenser stands for `grab` consecutive entries of the stage's list of `nun`; size = its tickets.
-    // (All waves of an XCD draw from one counter, and a counter serves only about nine million draws a second:
-    // 4096 waves on ONE counter took 460 us per sky unit, measured.)
+    // stages: -1 the lists (listed pixels, then early units), 0 this XCD's band, 1 another band, 7 late units, 8 done.
+    // The lists are ONE sequence of n_tasks + n_early entries with one counter for the whole chip -- and a counter
+    // answers some 4096 draws in a quarter of a millisecond, so no wave draws from it to find out that the lists
+    // are not for it: wave w of the launch takes entry w without asking, waves beyond the lists go straight to
+    // their band, and only a wave that has done an entry draws the next (the counter starts behind the waves'
+    // own entries: `bias`).
+    const uint32_t n_tasks = n_listed << px_log2, n_lists = n_tasks + n_early;
+    const uint32_t n_waves = gridDim.x * (kBlock / 64u), wave_id = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+    int stage = wave_id < n_lists ? -1 : 0;
+    uint32_t bias = 0;                                       // what a drawn ticket of the current stage is to be raised by
     uint32_t base = 0, size = 0, nun = 0, grab = 1, ticket = 0, band = xcd, helped = 0, late_helped = 0;
     const uint32_t *list = nullptr;                          // nullptr: the stage's entries are found otherwise
     uint32_t *ctr = nullptr;
@@ -2506,9 +2537,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         ctr = &work[kWorkLate + y];
     };
     auto enter = [&](int st) {
-        if (st == -2)      enter_list(n_listed << px_log2, 1u, kWorkHeavy);
-        else if (st == -1) enter_list(n_early, 1u, kWorkEarly);
-        else               enter_band(xcd);
+        if (st == -1) enter_list(n_lists, 1u, kWorkHeavy);
+        else          enter_band(xcd);
     };
     // The band with the most work left, by units still to hand out x what its units cost last time (wave-uniform;
     // -1: every band is used up).  The bands of an image cost very different amounts -- sky against silhouette --,
@@ -2529,17 +2559,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         return (klo | khi) ? (int)(klo & 7u) : -1;
     };
     enter(stage);
-    if (lane == 0 && size)
+    if (stage == -1)
+        ticket = wave_id;                                    // its own entry of the lists, no draw
+    else if (lane == 0 && size)
         ticket = atomicAdd(ctr, 1u);
-    // A listed pixel is the longest dependent chain of the launch (a dozen traversals one after another), and a
-    // launch over a small partition is as long as that chain: its wave issues ahead of the three it shares the SIMD with.
-    if (stage == -2 && A.task_prio)
-        __builtin_amdgcn_s_setprio(3);
     for (;;) {
-        uint32_t d = size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) : 0u;
+        uint32_t d = size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) + bias : 0u;
+        if (stage == -1)
+            bias = min(n_waves, n_lists);                    // every later ticket of the lists is a drawn one
         while (d >= size) {                                  // used up: on to the next stage
-            if (stage == -2)
-                __builtin_amdgcn_s_setprio(0);
+            bias = 0;
             if (stage < 0) {
                 enter(++stage);
             } else if (stage == 7) {                          // this slice of the late units is used up: the next
@@ -2568,18 +2597,23 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         if (stage >= 8)
             break;
         const bool in_band = stage == 0 || stage == 1;
+        // A listed pixel is the longest dependent chain of the launch (a dozen traversals one after another), and a
+        // launch over a small partition is as long as that chain: its wave issues ahead of the three it shares the SIMD with.
+        const bool prio = stage == -1 && d < n_tasks && A.task_prio;
+        if (prio)
+            __builtin_amdgcn_s_setprio(3);
         for (uint32_t k = 0; k < grab; k++) {
             const uint32_t idx = d * grab + k;
             if (idx >= nun)
                 break;
             uint32_t unit, only_px = kAllPixels;
-            if (stage == -2) {
+            if (stage == -1 && idx < n_tasks) {
                 // (a listed id is a unit of this shape: the min only keeps a damaged list harmless --
                 // unit n_units has no pixels)
                 unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.heavy_r[idx >> px_log2]), n_units);
                 only_px = idx & (px - 1u);
             } else if (stage == -1) {
-                const uint32_t slot = idx < n_early_a ? idx : A.fb.n_slots - 1u - (idx - n_early_a);
+                const uint32_t e = idx - n_tasks, slot = e < n_early_a ? e : A.fb.n_slots - 1u - (e - n_early_a);
                 unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.early_r[slot]), n_units);
             } else {
                 unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)list[base + idx]), n_units);
@@ -2593,20 +2627,24 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
             const unsigned long long cost_before = cost_sum;
 #endif
             const unsigned long long cost_at = cost_sum;
-            fused_unit<CULL>(A, env, unit, only_px, false, heavy_cost, early_cost, late_cost, lane, col, next_ctr, ticket, cost_sum, sp);
+            // (plenty = more than two tickets for every wave of the launch)
+            const bool draw_early = A.draw_early_ok && size - d > 2u * n_waves;
+            fused_unit<CULL>(A, env, unit, only_px, false, heavy_cost, early_cost, late_cost, draw_early, lane, col, next_ctr, ticket, cost_sum, sp);
             if (in_band)
                 band_cost += cost_sum - cost_at;
 #ifdef RT_STAMPS
             w_last_cost = cost_sum - cost_before;
-            if (stage == -2) {
+            if (stage == -1 && idx < n_tasks) {
                 const unsigned long long t_u1 = __builtin_amdgcn_s_memtime();
                 t_tasks_end = wall_clock64();
-                n_tasks++;
+                n_tasks_done++;
                 t_tasks_sum += t_u1 - t_u0;
                 t_task_max = t_u1 - t_u0 > t_task_max ? t_u1 - t_u0 : t_task_max;
             }
 #endif
         }
+        if (prio)
+            __builtin_amdgcn_s_setprio(0);
     }
     flush_band();
     if (A.fb.cnt_w && lane == 0 && cost_sum)
@@ -2622,7 +2660,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
             g_wave_log[0][wid] = w_begin;
             g_wave_log[1][wid] = wall_clock64();
             g_wave_log[2][wid] = sp.a[11];
-            g_wave_log[3][wid] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (unsigned long long)(blockIdx.x & 7u) << 8 | n_tasks << 16;
+            g_wave_log[3][wid] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) | (unsigned long long)(blockIdx.x & 7u) << 8 | n_tasks_done << 16;
             g_wave_log[4][wid] = w_last_start;
             g_wave_log[5][wid] = w_last_unit | w_last_stage << 32;
             g_wave_log[6][wid] = w_last_cost;
@@ -2630,7 +2668,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         atomicMax(&g_stamps[1][12], ~w_begin);
         atomicMax(&g_stamps[1][14], (unsigned long long)wall_clock64());
         if (t_tasks_end) atomicMax(&g_stamps[1][13], t_tasks_end);
-        if (n_tasks) { atomicAdd(&g_stamps[1][15], n_tasks); atomicAdd(&g_stamps[1][11], t_tasks_sum); atomicMax(&g_stamps[1][10], t_task_max); }
+        if (n_tasks_done) { atomicAdd(&g_stamps[1][15], n_tasks_done); atomicAdd(&g_stamps[1][11], t_tasks_sum); atomicMax(&g_stamps[1][10], t_task_max); }
     }
 #endif
 }
@@ -2877,6 +2915,7 @@ Knobs read_knobs()
     geti("RT_BAND_HELP", k.band_help);
     geti("RT_LATE_X16", k.late_x16);
     geti("RT_GRAB", k.grab);
+    geti("RT_DRAW_EARLY", k.draw_early);
     geti("RT_GRAB_LATE", k.grab_late);
     return k;
 }
@@ -3012,6 +3051,7 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
     A.grab = (uint32_t)std::min(64, std::max(1, knobs.grab));
     A.grab_late = (uint32_t)std::min(64, std::max(1, knobs.grab_late));
     A.band_units = batch_band_units(units);
+    A.draw_early_ok = knobs.draw_early != 0;
     // the previous launch's flags as this launch's lists (stream-ordered: that launch is over, this one not begun)
     (void)hipMemsetAsync(A.fb.lists_w, 0, sizeof(BatchLists), s);
     k_classify<<<(units + kClassifyPerBlock - 1u) / kClassifyPerBlock, 256, 0, s>>>(A.fb.flag_r, A.fb.flags_valid, units, A.band_units,

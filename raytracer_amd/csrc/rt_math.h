@@ -277,6 +277,8 @@ struct CameraRec {
     v3 pos, up, front, right;
     int32_t res_x, res_y;
     float n;
+    float aspect;      // (float)res_x / res_y as Camera::generateRay computes it per ray (Camera.cu:19): a ray-independent
+                       // IEEE division, done once at rt_set_camera -- the same bits
 };
 
 } // namespace rt

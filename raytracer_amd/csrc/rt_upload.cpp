@@ -594,6 +594,7 @@ CameraRec make_camera(const rt_camera_desc *a)
     c.res_x = a->res_x;                                        // Camera.cu:9
     c.res_y = a->res_y;
     c.n = a->near_;                                            // Camera.cu:11
+    c.aspect = (float)c.res_x / c.res_y;                       // Camera.cu:19, hoisted
     c.right = normalize(cross(c.front, c.up));                 // Camera.cu:12
     c.up = normalize(cross(c.right, c.front));                 // Camera.cu:13
     return c;

@@ -282,7 +282,7 @@ def main():
         # What the kernel is closest to: the VALU pipe.  Per launch, the cycles its instruction mix occupies a SIMD's
         # VALU for (committed counters x measured per-class cycles, tools/valu_ceiling.py) against the cycles the
         # launch had on every SIMD; the duration is live, and the streams' launches share the chip.
-        mix = valu_mix(cfg.name, kernel)
+        mix = valu_mix(cfg.name, kernel) if spp == cfg.spp else None     # the counters were taken at the config's own spp
         if mix and k_ms > 0:
             prop = torch.cuda.get_device_properties(dev)
             simds = prop.multi_processor_count * 4

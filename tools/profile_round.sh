@@ -22,8 +22,8 @@ for c in $CONFIGS; do
   case $c in
     c2) B="--config c2 --steps 5 --warmup 2";           A="--config c2 --steps 2 --warmup 1 --no-cpu";;
     c3) B="--config c3 --steps 3 --warmup 1";           A="--config c3 --steps 1 --warmup 1 --no-cpu";;
-    c4) B="--config c4 --spp 64 --steps 2 --warmup 1";  A="--config c4 --spp 64 --steps 1 --warmup 1 --no-cpu";;
-    c5) B="--config c5 --spp 16 --steps 2 --warmup 1";  A="--config c5 --spp 16 --steps 1 --warmup 1 --no-cpu";;
+    c4) B="--config c4 --steps 2 --warmup 1";           A="--config c4 --steps 1 --warmup 1 --no-cpu";;
+    c5) B="--config c5 --steps 2 --warmup 1";           A="--config c5 --steps 1 --warmup 1 --no-cpu";;
     *)  B="--config $c --steps 3 --warmup 1";           A="--config $c --steps 1 --warmup 1 --no-cpu";;
   esac
   echo "== $c: bench"; date +%T

@@ -15,7 +15,7 @@ MIX3=SQ_INSTS_VALU,SQ_INSTS_VALU_ADD_F64,SQ_INSTS_VALU_MUL_F64,SQ_INSTS_VALU_FMA
 for c in $CONFIGS; do
   case $c in
     c4) A="--config c4 --spp 64 --steps 1 --warmup 1 --no-cpu";;
-    c5) A="--config c5 --spp 16 --steps 1 --warmup 1 --no-cpu";;
+    c5) A="--config c5 --spp 64 --steps 1 --warmup 1 --no-cpu";;
     *)  A="--config $c --steps 1 --warmup 1 --no-cpu";;
   esac
   n=1

@@ -16,7 +16,7 @@ timeout -k 10 200 build/valu_microbench $O/microbench.csv > $O/microbench.txt 2>
 for c in $CONFIGS; do
   case $c in
     c4) A="--config c4 --spp 64 --steps 1 --warmup 1 --no-cpu";;
-    c5) A="--config c5 --spp 16 --steps 1 --warmup 1 --no-cpu";;
+    c5) A="--config c5 --spp 64 --steps 1 --warmup 1 --no-cpu";;
     *)  A="--config $c --steps 1 --warmup 1 --no-cpu";;
   esac
   echo "== $c pmc mix"; date +%T

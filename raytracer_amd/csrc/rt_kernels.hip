@@ -1946,14 +1946,26 @@ __device__ __forceinline__ void write_last(const BatchArgs &A, const PrimaryTrac
     A.v.last_draws[p] = o.delta[h];
 }
 
+// A wave's DESK: what it knows about the dispensers, the lists and its own sums lives in LDS while a unit is under
+// way, one row of words per wave, and is read back afterwards -- a unit needs every register there is, and two dozen
+// wave-uniform values kept alive across it were what the compiler spilled (first the SGPRs into VGPR lanes, then
+// VGPRs to scratch, and the scratch of 4096 waves no longer fit the L2s).
+enum : int {
+    kDkStage, kDkBias, kDkSize, kDkNun, kDkGrab, kDkBand, kDkHelped, kDkLateHelped, kDkK, kDkD, kDkListKind, kDkListOff,
+    kDkCtr,                          // slot of the dispenser the next ticket comes from
+    kDkDraw,                         // 0: this unit draws no ticket, 1: behind the shadow rays, 2: at its start
+    kDkInBand,                       // the unit's cost counts for its band's sum
+    kDkBandCostLo, kDkBandCostHi, kDkCostLo, kDkCostHi,
+    kDkHeavy, kDkEarly, kDkLate,     // the launch's cost thresholds (feedback)
+    kDkWords = 32
+};
+
 template <bool CULL>
 __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                           uint32_t only_px, bool skip_listed, uint32_t heavy_cost, uint32_t early_cost,
-                                           uint32_t late_cost, bool draw_early, uint32_t lane, uint32_t *col, uint32_t *next_counter,
-                                           uint32_t &ticket, unsigned long long &cost_sum, Stamps &sp)
+                                           uint32_t only_px, uint32_t lane, uint32_t *col, uint32_t *dk,
+                                           uint32_t *__restrict__ work, uint32_t &ticket, Stamps &sp)
 {
     // only_px = kAllPixels: the whole unit; else only its pixel `only_px` (a listed unit, split by pixel).
-    // skip_listed: units the previous launch listed were handed out pixel by pixel already.
     const DevView &v = A.v;
     const uint32_t L = (uint32_t)v.n_lights;
     const float E = A.T.tv.extent;
@@ -1985,20 +1997,14 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         RT_STAMP(stamp_arrived_v(pix[h]); stamp_arrived_v(base_c[h]); stamp_arrived_v(dhat[h]));
     }
     RT_MARK(sp, 16);
-    const bool listed = skip_listed && A.fb.flag_r[unit] != 0u;
-    if (listed) {                                            // its pixels went out one by one, first
-        if (lane == 0 && next_counter)
-            ticket = atomicAdd(next_counter, 1u);
-        return;
-    }
     // The NEXT unit's ticket.  A draw takes microseconds to come back (the counters live on the memory side), so
-    // while its dispenser still has plenty to hand out a wave draws now, behind the prologue's loads, and has the
-    // answer long before it needs it.  Near the dispenser's end that would leave every wave with two units to do
-    // when it runs dry -- the one it is in and the one it holds a ticket for -- and the launch's tail two units
-    // long (measured on an eighth of C3: waves ended over 600 us of 2400); there the draw waits until just before
-    // the epilogue (below).
-    if (draw_early && lane == 0 && next_counter)
-        ticket = atomicAdd(next_counter, 1u);
+    // while its dispenser still has plenty to hand out a wave may draw now, behind the prologue's loads
+    // (RT_DRAW_EARLY=1), and has the answer long before it needs it.  Near the dispenser's end that would leave
+    // every wave with two units to do when it runs dry -- the one it is in and the one it holds a ticket for -- and
+    // the launch's tail two units long (measured on an eighth of C3: waves ended over 600 us of 2400); there, and by
+    // default everywhere, the draw waits until just before the epilogue (below).
+    if (lane == 0 && dk[kDkDraw] == 2u)
+        ticket = atomicAdd(&work[dk[kDkCtr]], 1u);
 
     // Phases P and H share ONE call site of the closest-hit traversal (one copy of its loop in the
     // instruction cache).  mode 0, 1: the two prediction rounds; mode 2: the pixels still open
@@ -2286,8 +2292,8 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
         RT_MARK(sp, 22);
     }
-    if (!draw_early && lane == 0 && next_counter)            // the next unit's ticket, late form: back behind the epilogue
-        ticket = atomicAdd(next_counter, 1u);
+    if (lane == 0 && dk[kDkDraw] == 1u)                      // the next unit's ticket, late form: back behind the epilogue
+        ticket = atomicAdd(&work[dk[kDkCtr]], 1u);
     RT_MARK(sp, 21);
     // PathTracer.cu:73 with beta = 1, res = 0; a miss returns 0 (:64).  Every sample's share of the
     // running mean px = frac2 * prev + frac1 * c (kernel.cu:65-66,75) goes to LDS: its term
@@ -2362,7 +2368,17 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
     // feedback for the next launch: what this unit cost, and whether it should go out first, by pixel
     // (a pixel task costs a quarter of the lanes but much less than its unit: listed again from a quarter on)
-    cost_sum += cost;
+    {   // (every lane writes the same words)
+        const uint32_t lo = dk[kDkCostLo], nlo = lo + cost;
+        dk[kDkCostLo] = nlo;
+        if (nlo < lo) dk[kDkCostHi] = dk[kDkCostHi] + 1u;
+        if (dk[kDkInBand]) {
+            const uint32_t blo = dk[kDkBandCostLo], nblo = blo + cost;
+            dk[kDkBandCostLo] = nblo;
+            if (nblo < blo) dk[kDkBandCostHi] = dk[kDkBandCostHi] + 1u;
+        }
+    }
+    const uint32_t heavy_cost = dk[kDkHeavy], early_cost = dk[kDkEarly], late_cost = dk[kDkLate];
     if (A.fb.cnt_w && lane == 0 && cost >= (only_px == kAllPixels ? heavy_cost : heavy_cost >> 2)) {
         if (atomicExch(&A.fb.flag_w[unit], 1u) == 0u) {
             const uint32_t slot = atomicAdd(&A.fb.cnt_w->n_heavy, 1u);
@@ -2454,9 +2470,12 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
 #endif
     const uint32_t px_log2 = 7u - A.ss_log2, px = 1u << px_log2;
     const uint32_t n_units = (A.n + px - 1u) / px;
+    __shared__ uint32_t s_desk[kBlock / 64u][kDkWords];
+    uint32_t *const dk = s_desk[threadIdx.x >> 6];            // (plain LDS accesses, fenced by compiler barriers: a volatile
+                                                             // pointer loses its address space and turns into flat accesses)
+    auto desk = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)dk[i]); };
     // What the previous launch of this shape found costly: those units first, one pixel per task.
     uint32_t n_listed = 0, n_early_a = 0, n_early = 0, heavy_cost = 0xffffffffu, early_cost = 0xffffffffu, late_cost = 0u;
-    unsigned long long cost_sum = 0ull;
     const BatchLists *const LS = A.fb.lists;
     const bool fb_valid = A.fb.cnt_w && A.fb.flags_valid;    // the lists and flags are the previous launch's, of this shape
     if (A.fb.cnt_w) {
@@ -2479,73 +2498,61 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         if (blockIdx.x == 0 && threadIdx.x == 0)
             A.fb.cnt_w->pad = A.ss_log2 + 1u;                // (n_heavy and total were zeroed by the host)
     }
-    // Stage -2: the listed units' pixels (one counter for the whole chip); stage -1: the early units, whole,
-    // costliest class first; then this XCD's band of ordinary units, then the other XCDs' bands, whichever has the
-    // most work left; last the late units, in eight slices.  The bands' and the late units' lists are k_classify's.
-    // One ticket ahead throughout.
-    const uint32_t per = A.band_units, xcd = blockIdx.x & 7u;
-    const uint32_t n_late = LS->n_late, late_per = (n_late + 7u) / 8u;
-    // stages: -1 the lists (listed pixels, then early units), 0 this XCD's band, 1 another band, 7 late units, 8 done.
+    // Stage -1: the lists -- the listed units' pixels, then the early units, whole, costliest class first (one
+    // counter for the whole chip); stage 0: this XCD's band of ordinary units; stage 1: the other XCDs' bands,
+    // whichever has the most work left; stage 7: the late units, in eight slices; 8: done.  The bands' and the late
+    // units' lists are k_classify's.  One ticket ahead throughout.
     // The lists are ONE sequence of n_tasks + n_early entries with one counter for the whole chip -- and a counter
     // answers some 4096 draws in a quarter of a millisecond, so no wave draws from it to find out that the lists
     // are not for it: wave w of the launch takes entry w without asking, waves beyond the lists go straight to
     // their band, and only a wave that has done an entry draws the next (the counter starts behind the waves'
     // own entries: `bias`).
-    const uint32_t n_tasks = n_listed << px_log2, n_lists = n_tasks + n_early;
+    struct Disp {                                            // the desk's dispatch words, in registers between two units only
+        int stage;
+        uint32_t bias, size, nun, grab, band, helped, late_helped, k, d, list_kind, list_off, ctr;
+    };
+    const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t n_waves = gridDim.x * (kBlock / 64u), wave_id = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
-    int stage = wave_id < n_lists ? -1 : 0;
-    uint32_t bias = 0;                                       // what a drawn ticket of the current stage is to be raised by
-    uint32_t base = 0, size = 0, nun = 0, grab = 1, ticket = 0, band = xcd, helped = 0, late_helped = 0;
-    const uint32_t *list = nullptr;                          // nullptr: the stage's entries are found otherwise
-    uint32_t *ctr = nullptr;
-    // lane y < 8 (and its copies): what a unit of band y cost on average in the previous launch of this shape, x 16 (>= 1)
-    uint32_t band_w = 16u;
-    if (fb_valid) {
-        const uint32_t y = lane & 7u, bsz = LS->n_norm[y];
-        const FbCounts *cr = A.fb.cnt_r;
-        if (cr->total && bsz)
-            band_w = (uint32_t)std::min<unsigned long long>(16ull * cr->band[y] / bsz + 1ull, 0xffffffull);
-    }
-    auto enter_list = [&](uint32_t n, uint32_t g, int slot) {
-        base = 0; nun = n; grab = g; size = (n + g - 1u) / g; ctr = &work[slot]; list = nullptr;
+    auto n_tasks_of = [&]() { return min((uint32_t)__builtin_amdgcn_readfirstlane((int)(fb_valid && A.fb.cnt_r->total ? A.fb.cnt_r->n_heavy : 0u)), A.fb.n_slots) << px_log2; };
+    auto enter_list = [&](Disp &D, uint32_t n) {
+        D.nun = n; D.grab = 1u; D.size = n; D.ctr = (uint32_t)kWorkHeavy; D.list_kind = 0u; D.list_off = 0u;
     };
     // what the units this wave took from a band cost: added to the band's sum when the wave leaves it (the next
     // launch's helpers go by these sums)
-    unsigned long long band_cost = 0ull;
-    auto flush_band = [&]() {
-        if (A.fb.cnt_w && lane == 0 && band_cost)
-            atomicAdd(&A.fb.cnt_w->band[band], band_cost);
-        band_cost = 0ull;
+    auto flush_band = [&](uint32_t band) {
+        const unsigned long long bc = ((unsigned long long)desk(kDkBandCostHi) << 32) | desk(kDkBandCostLo);
+        if (A.fb.cnt_w && lane == 0 && bc)
+            atomicAdd(&A.fb.cnt_w->band[band], bc);
+        dk[kDkBandCostLo] = 0u; dk[kDkBandCostHi] = 0u;
     };
-    auto enter_band = [&](uint32_t y) {
-        flush_band();
-        band = y;
-        base = 0;
-        list = A.fb.norm + (size_t)y * per;
-        nun = (uint32_t)__builtin_amdgcn_readfirstlane((int)LS->n_norm[y]);
-        grab = A.grab;
-        size = (nun + grab - 1u) / grab;
-        ctr = &work[y];
+    auto enter_band = [&](Disp &D, uint32_t y) {
+        flush_band(D.band);
+        D.band = y;
+        D.list_kind = 1u; D.list_off = y * A.band_units;
+        D.nun = (uint32_t)__builtin_amdgcn_readfirstlane((int)LS->n_norm[y]);
+        D.grab = A.grab;
+        D.size = (D.nun + D.grab - 1u) / D.grab;
+        D.ctr = y;
     };
-    auto enter_late = [&](uint32_t y) {
-        flush_band();
-        base = 0;
-        list = A.fb.late + y * late_per;
-        nun = y * late_per < n_late ? min(late_per, n_late - y * late_per) : 0u;
-        grab = A.grab_late;
-        size = (nun + grab - 1u) / grab;
-        ctr = &work[kWorkLate + y];
-    };
-    auto enter = [&](int st) {
-        if (st == -1) enter_list(n_lists, 1u, kWorkHeavy);
-        else          enter_band(xcd);
+    auto enter_late = [&](Disp &D, uint32_t y) {
+        flush_band(D.band);
+        const uint32_t n_late = (uint32_t)__builtin_amdgcn_readfirstlane((int)LS->n_late), late_per = (n_late + 7u) / 8u;
+        D.list_kind = 2u; D.list_off = y * late_per;
+        D.nun = y * late_per < n_late ? min(late_per, n_late - y * late_per) : 0u;
+        D.grab = A.grab_late;
+        D.size = (D.nun + D.grab - 1u) / D.grab;
+        D.ctr = (uint32_t)kWorkLate + y;
     };
     // The band with the most work left, by units still to hand out x what its units cost last time (wave-uniform;
     // -1: every band is used up).  The bands of an image cost very different amounts -- sky against silhouette --,
     // and helpers that go round in a fixed order reach the costliest band last.
     auto pick = [&]() -> int {
-        const uint32_t y = lane & 7u;
-        const uint32_t tickets = (LS->n_norm[y] + A.grab - 1u) / A.grab;
+        const uint32_t y = lane & 7u, bsz = LS->n_norm[y];
+        // what a unit of band y cost on average in the previous launch of this shape, x 16 (>= 1)
+        uint32_t band_w = 16u;
+        if (fb_valid && A.fb.cnt_r->total && bsz)
+            band_w = (uint32_t)std::min<unsigned long long>(16ull * A.fb.cnt_r->band[y] / bsz + 1ull, 0xffffffull);
+        const uint32_t tickets = (bsz + A.grab - 1u) / A.grab;
         const uint32_t c = __hip_atomic_load(&work[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t rem = tickets - min(c, tickets);
         unsigned long long key = rem ? (((unsigned long long)rem * band_w) << 3) | y : 0ull;
@@ -2558,97 +2565,128 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(key >> 32));
         return (klo | khi) ? (int)(klo & 7u) : -1;
     };
-    enter(stage);
-    if (stage == -1)
-        ticket = wave_id;                                    // its own entry of the lists, no draw
-    else if (lane == 0 && size)
-        ticket = atomicAdd(ctr, 1u);
-    for (;;) {
-        uint32_t d = size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) + bias : 0u;
-        if (stage == -1)
-            bias = min(n_waves, n_lists);                    // every later ticket of the lists is a drawn one
-        while (d >= size) {                                  // used up: on to the next stage
-            bias = 0;
-            if (stage < 0) {
-                enter(++stage);
-            } else if (stage == 7) {                          // this slice of the late units is used up: the next
-                if (++late_helped >= 8u) {
-                    stage = 8;
-                    break;
-                }
-                enter_late((xcd + late_helped) & 7u);
-            } else {
-                const int y = A.band_help ? pick() : ++helped < 8u ? (int)((xcd + helped) & 7u) : -1;
-                if (y >= 0) {
-                    stage = 1;
-                    enter_band((uint32_t)y);
-                } else {                                     // every band is used up: what was kept for last
-                    stage = 7;
-                    enter_late(xcd);
-                }
-            }
-            d = size;
-            if (size) {
-                if (lane == 0)
-                    ticket = atomicAdd(ctr, 1u);
-                d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
-            }
+    uint32_t ticket = 0;
+    {
+        const uint32_t n_lists = (n_listed << px_log2) + n_early;
+        Disp D = {};
+        D.band = xcd;
+        dk[kDkBandCostLo] = 0u; dk[kDkBandCostHi] = 0u; dk[kDkCostLo] = 0u; dk[kDkCostHi] = 0u;
+        dk[kDkHeavy] = heavy_cost; dk[kDkEarly] = early_cost; dk[kDkLate] = late_cost;
+        D.stage = wave_id < n_lists ? -1 : 0;
+        if (D.stage == -1) {
+            enter_list(D, n_lists);
+            ticket = wave_id;                                // its own entry of the lists, no draw
+        } else {
+            enter_band(D, xcd);
+            if (lane == 0 && D.size)
+                ticket = atomicAdd(&work[D.ctr], 1u);
         }
-        if (stage >= 8)
-            break;
-        const bool in_band = stage == 0 || stage == 1;
+        D.k = D.grab;                                        // (no ticket in hand yet: the first pass of the loop takes `ticket`)
+        dk[kDkStage] = (uint32_t)D.stage; dk[kDkBias] = 0u; dk[kDkSize] = D.size; dk[kDkNun] = D.nun; dk[kDkGrab] = D.grab;
+        dk[kDkBand] = D.band; dk[kDkHelped] = 0u; dk[kDkLateHelped] = 0u; dk[kDkK] = D.k; dk[kDkD] = 0u;
+        dk[kDkListKind] = D.list_kind; dk[kDkListOff] = D.list_off; dk[kDkCtr] = D.ctr;
+    }
+    for (;;) {
+        asm volatile("" ::: "memory");                      // the desk is read afresh after every unit
+        Disp D;
+        D.stage = (int)desk(kDkStage); D.bias = desk(kDkBias); D.size = desk(kDkSize); D.nun = desk(kDkNun);
+        D.grab = desk(kDkGrab); D.band = desk(kDkBand); D.helped = desk(kDkHelped); D.late_helped = desk(kDkLateHelped);
+        D.k = desk(kDkK); D.d = desk(kDkD); D.list_kind = desk(kDkListKind); D.list_off = desk(kDkListOff); D.ctr = desk(kDkCtr);
+        const uint32_t n_tasks = n_tasks_of();
+        if (D.k >= D.grab || D.d * D.grab + D.k >= D.nun) {  // this ticket is used up: the one drawn meanwhile
+            D.k = 0;
+            D.d = D.size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) + D.bias : 0u;
+            if (D.stage == -1)
+                D.bias = min(n_waves, D.size);               // every later ticket of the lists is a drawn one
+            while (D.d >= D.size) {                          // used up: on to the next stage
+                D.bias = 0;
+                if (D.stage < 0) {
+                    D.stage = 0;
+                    enter_band(D, xcd);
+                } else if (D.stage == 7) {                    // this slice of the late units is used up: the next
+                    if (++D.late_helped >= 8u) {
+                        D.stage = 8;
+                        break;
+                    }
+                    enter_late(D, (xcd + D.late_helped) & 7u);
+                } else {
+                    const int y = A.band_help ? pick() : ++D.helped < 8u ? (int)((xcd + D.helped) & 7u) : -1;
+                    if (y >= 0) {
+                        D.stage = 1;
+                        enter_band(D, (uint32_t)y);
+                    } else {                                 // every band is used up: what was kept for last
+                        D.stage = 7;
+                        enter_late(D, xcd);
+                    }
+                }
+                D.d = D.size;
+                if (D.size) {
+                    if (lane == 0)
+                        ticket = atomicAdd(&work[D.ctr], 1u);
+                    D.d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
+                }
+            }
+            if (D.stage >= 8)
+                break;
+        }
+        const uint32_t idx = D.d * D.grab + D.k;
+        D.k++;
+        uint32_t unit, only_px = kAllPixels;
+        if (D.stage == -1 && idx < n_tasks) {
+            // (a listed id is a unit of this shape: the min only keeps a damaged list harmless --
+            // unit n_units has no pixels)
+            unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.heavy_r[idx >> px_log2]), n_units);
+            only_px = idx & (px - 1u);
+        } else if (D.stage == -1) {
+            const uint32_t n_ea = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.cnt_r->n_early_a), A.fb.n_slots);
+            const uint32_t e = idx - n_tasks, slot = e < n_ea ? e : A.fb.n_slots - 1u - (e - n_ea);
+            unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.early_r[slot]), n_units);
+        } else {
+            const uint32_t *const list = D.list_kind == 1u ? A.fb.norm : A.fb.late;
+            unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)list[D.list_off + idx]), n_units);
+        }
+        // the ticket after this one is drawn inside the last unit of this one
+        // (early form only while the dispenser has plenty left: more than two tickets for every wave of the launch)
+        const bool last_of_ticket = D.k >= D.grab || idx + 1u >= D.nun;
+        const bool draw_early = A.draw_early_ok && D.size - D.d > 2u * n_waves;
         // A listed pixel is the longest dependent chain of the launch (a dozen traversals one after another), and a
         // launch over a small partition is as long as that chain: its wave issues ahead of the three it shares the SIMD with.
-        const bool prio = stage == -1 && d < n_tasks && A.task_prio;
+        const bool prio = D.stage == -1 && idx < n_tasks && A.task_prio;
+        dk[kDkStage] = (uint32_t)D.stage; dk[kDkBias] = D.bias; dk[kDkSize] = D.size; dk[kDkNun] = D.nun; dk[kDkGrab] = D.grab;
+        dk[kDkBand] = D.band; dk[kDkHelped] = D.helped; dk[kDkLateHelped] = D.late_helped; dk[kDkK] = D.k; dk[kDkD] = D.d;
+        dk[kDkListKind] = D.list_kind; dk[kDkListOff] = D.list_off; dk[kDkCtr] = D.ctr;
+        dk[kDkDraw] = last_of_ticket ? (draw_early ? 2u : 1u) : 0u;
+        dk[kDkInBand] = (D.stage == 0 || D.stage == 1) ? 1u : 0u;
+        asm volatile("" ::: "memory");
         if (prio)
             __builtin_amdgcn_s_setprio(3);
-        for (uint32_t k = 0; k < grab; k++) {
-            const uint32_t idx = d * grab + k;
-            if (idx >= nun)
-                break;
-            uint32_t unit, only_px = kAllPixels;
-            if (stage == -1 && idx < n_tasks) {
-                // (a listed id is a unit of this shape: the min only keeps a damaged list harmless --
-                // unit n_units has no pixels)
-                unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.heavy_r[idx >> px_log2]), n_units);
-                only_px = idx & (px - 1u);
-            } else if (stage == -1) {
-                const uint32_t e = idx - n_tasks, slot = e < n_early_a ? e : A.fb.n_slots - 1u - (e - n_early_a);
-                unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.fb.early_r[slot]), n_units);
-            } else {
-                unit = min((uint32_t)__builtin_amdgcn_readfirstlane((int)list[base + idx]), n_units);
-            }
-            // the ticket after this one is drawn inside the last unit of this one
-            uint32_t *const next_ctr = (k + 1u == grab || idx + 1u >= nun) ? ctr : nullptr;
 #ifdef RT_STAMPS
-            const unsigned long long t_u0 = __builtin_amdgcn_s_memtime();
-            w_last_start = wall_clock64();
-            w_last_unit = unit; w_last_stage = (unsigned long long)(stage + 2);
-            const unsigned long long cost_before = cost_sum;
+        const unsigned long long t_u0 = __builtin_amdgcn_s_memtime();
+        w_last_start = wall_clock64();
+        w_last_unit = unit; w_last_stage = (unsigned long long)(D.stage + 2);
+        const unsigned long long cost_before = desk(kDkCostLo);
+        const bool is_task = D.stage == -1 && idx < n_tasks;
 #endif
-            const unsigned long long cost_at = cost_sum;
-            // (plenty = more than two tickets for every wave of the launch)
-            const bool draw_early = A.draw_early_ok && size - d > 2u * n_waves;
-            fused_unit<CULL>(A, env, unit, only_px, false, heavy_cost, early_cost, late_cost, draw_early, lane, col, next_ctr, ticket, cost_sum, sp);
-            if (in_band)
-                band_cost += cost_sum - cost_at;
-#ifdef RT_STAMPS
-            w_last_cost = cost_sum - cost_before;
-            if (stage == -1 && idx < n_tasks) {
-                const unsigned long long t_u1 = __builtin_amdgcn_s_memtime();
-                t_tasks_end = wall_clock64();
-                n_tasks_done++;
-                t_tasks_sum += t_u1 - t_u0;
-                t_task_max = t_u1 - t_u0 > t_task_max ? t_u1 - t_u0 : t_task_max;
-            }
-#endif
-        }
+        fused_unit<CULL>(A, env, unit, only_px, lane, col, dk, work, ticket, sp);
         if (prio)
             __builtin_amdgcn_s_setprio(0);
+#ifdef RT_STAMPS
+        w_last_cost = (uint32_t)(desk(kDkCostLo) - (uint32_t)cost_before);
+        if (is_task) {
+            const unsigned long long t_u1 = __builtin_amdgcn_s_memtime();
+            t_tasks_end = wall_clock64();
+            n_tasks_done++;
+            t_tasks_sum += t_u1 - t_u0;
+            t_task_max = t_u1 - t_u0 > t_task_max ? t_u1 - t_u0 : t_task_max;
+        }
+#endif
     }
-    flush_band();
-    if (A.fb.cnt_w && lane == 0 && cost_sum)
-        atomicAdd(&A.fb.cnt_w->total, cost_sum);
+    flush_band(desk(kDkBand));
+    {
+        const unsigned long long cost_sum = ((unsigned long long)desk(kDkCostHi) << 32) | desk(kDkCostLo);
+        if (A.fb.cnt_w && lane == 0 && cost_sum)
+            atomicAdd(&A.fb.cnt_w->total, cost_sum);
+    }
 #ifdef RT_STAMPS
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     sp.a[0] = t_end - t_begin;

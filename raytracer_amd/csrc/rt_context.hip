@@ -81,7 +81,8 @@ struct Lane {
     uint32_t *bheavy[3] = {nullptr, nullptr, nullptr};
     uint32_t *bearly[3] = {nullptr, nullptr, nullptr};
     uint32_t *bnorm = nullptr, *blate = nullptr;   // k_classify's lists for the launch at hand (8 x band_units, units)
-    BatchLists *blists = nullptr;
+    BatchLists *blists = nullptr;                  // two: a launch's k_batch zeroes the other for the next launch's k_classify
+    uint32_t bl_seq = 0;
     uint32_t bfb_shape[3] = {0, 0, 0};              // 1 + ss_log2 of the launch that wrote each set (0: none)
     uint32_t *bflag[3] = {nullptr, nullptr, nullptr};
     FbCounts *bcnt = nullptr;            // [3]
@@ -247,7 +248,9 @@ int alloc_feedback(rt_context *c, Lane &L)
     // (units of the smallest shape bound every shape's count; a band is rounded up to 64 units)
     if ((rc = dalloc(c, c->part_allocs, L.bnorm, units + 8 * 64))) return rc;
     if ((rc = dalloc(c, c->part_allocs, L.blate, units))) return rc;
-    if ((rc = dalloc(c, c->part_allocs, L.blists, 1))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, L.blists, 2))) return rc;
+    RT_HIP(c, hipMemset(L.blists, 0, 2 * sizeof(BatchLists)));
+    L.bl_seq = 0;
     L.bfb_shape[0] = L.bfb_shape[1] = L.bfb_shape[2] = 0;
     L.bfb_slots = (uint32_t)units;
     L.bfb_seq = 0;
@@ -344,25 +347,29 @@ ChunkFeedback next_feedback(Lane &L)
 }
 
 // Feedback sets of k_batch rotate by launch: read what the previous launch wrote, write the next
-// set; the set after that is zeroed here, on the lane's stream, for the launch that will write it.
+// set; the set after that is zeroed by this launch's k_classify for the launch that will write it.
+// Called once per launch that does take place (rt_render): the lane's two list headers alternate, and
+// each launch's k_batch zeroes the one its successor's k_classify fills.
 int next_batch_feedback(rt_context *c, Lane &L, BatchFeedback &f, uint32_t ss_log2)
 {
     const int r = (int)((L.bfb_seq + 2u) % 3u), w = (int)(L.bfb_seq % 3u), z = (int)((L.bfb_seq + 1u) % 3u);
     f.cnt_r = L.bcnt + r; f.heavy_r = L.bheavy[r]; f.early_r = L.bearly[r]; f.flag_r = L.bflag[r];
     f.n_slots = L.bfb_slots;
-    f.lists = f.lists_w = L.blists; f.norm = f.norm_w = L.bnorm; f.late = f.late_w = L.blate;
+    f.lists = f.lists_w = L.blists + (L.bl_seq & 1u); f.lists_next = L.blists + ((L.bl_seq + 1u) & 1u);
+    f.norm = f.norm_w = L.bnorm; f.late = f.late_w = L.blate;
+    L.bl_seq++;
     if (!c->batch_feedback) {                // ordering off: every unit is ordinary, nothing is recorded
         f.cnt_w = nullptr; f.heavy_w = nullptr; f.early_w = nullptr; f.flag_w = nullptr;
+        f.cnt_z = nullptr; f.flag_z = nullptr;
         f.flags_valid = 0;
         return RT_OK;
     }
     f.cnt_w = L.bcnt + w; f.heavy_w = L.bheavy[w]; f.early_w = L.bearly[w]; f.flag_w = L.bflag[w];
+    f.cnt_z = L.bcnt + z; f.flag_z = L.bflag[z];
     // the lists of set r are for this launch only if a launch of the same shape (samples per wave) wrote them
     f.flags_valid = L.bfb_shape[r] == ss_log2 + 1u ? 1u : 0u;
     L.bfb_shape[w] = ss_log2 + 1u;
     L.bfb_shape[z] = 0;
-    RT_HIP(c, hipMemsetAsync(L.bcnt + z, 0, sizeof(FbCounts), L.stream));
-    RT_HIP(c, hipMemsetAsync(L.bflag[z], 0, (size_t)L.bfb_slots * sizeof(uint32_t), L.stream));
     L.bfb_seq++;
     return RT_OK;
 }

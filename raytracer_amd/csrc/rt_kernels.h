@@ -80,7 +80,7 @@ struct ChunkFeedback {
 // them, split by pixel: each pixel of a listed unit is a task of its own (a quarter of the lanes,
 // but rays through one pixel walk far less of the tree together than rays along a silhouette), so
 // four waves share what one wave would have carried.  Sets rotate by launch (r: written by the
-// previous launch, w: written now, z: zeroed by the host for the launch after).  Only an ordering
+// previous launch, w: written now, z: zeroed by k_classify for the launch after).  Only an ordering
 // hint: every pixel-sample is processed exactly once whatever the sets hold.
 // Costly units below that threshold ("early": >= early_x4 / 4 times the mean unit cost) are handed out whole, right
 // after the listed pixels and before the bands, costliest class first: a launch then ends with cheap units, not with
@@ -104,6 +104,9 @@ struct BatchFeedback {
     const uint32_t *late;                // lists->n_late units, handed out when every band is used up
     uint32_t *norm_w, *late_w;           // (the same arrays, for k_classify)
     BatchLists *lists_w;
+    BatchLists *lists_next;              // the other of the lane's two: zeroed by k_batch for the next launch's k_classify
+    FbCounts *cnt_z;                     // the set after `w`: zeroed by k_classify for the launch that will write it
+    uint32_t *flag_z;                    // (nullptr: no feedback)
     uint32_t flags_valid;                // 1: flag_r was written by a launch of this shape; 0: every unit is ordinary
 };
 

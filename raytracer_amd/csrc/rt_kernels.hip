@@ -372,13 +372,21 @@ __device__ __forceinline__ void after_triangles(const TravArgs &A, RayPair &r)
 // lvloff: lane l holds the first group of level l.
 // COOP: called by all four waves of the block with identical rays; s_best is the block's
 // LDS merge array (128 entries).  Every wave returns the block's common answer.
-template <bool CULL, bool COOP, bool ORDER = true, bool LIGHTS = false>
+template <bool CULL, bool COOP, bool ORDER = true, bool LIGHTS = false, bool OWN_BASES = false>
 __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, RayPair &r,
                                          uint32_t lane, uint32_t wib,
                                          unsigned long long *s_best, uint32_t &cost, Stamps &sp)
 {
     const TreeView &tv = A.tv;
     const bool sorted_ok = A.sorted_planes != 0;
+    // OWN_BASES: the two base pointers of the loops below as values of their own.  Left as parts of the argument
+    // block they sit in registers eight dwords at a time, and a spill of one restores all eight inside the loop
+    // (k_batch's five-wave build: eight v_readlane per triangle record for one 64-bit base, C5 -2.6 %).  The
+    // four-wave build allocates better without (C3 +1.6 %), so k_batch asks for it by its build.
+    const TriRec *tris = A.tris;
+    const NodeGroup *groups = tv.groups;
+    if (OWN_BASES)
+        asm volatile("" : "+s"(tris), "+s"(groups));
     RT_STAT(0, 1);
     RT_COUNT(sp, 12);
     unsigned long long pub0 = 0, pub1 = 0;       // what this wave last saw or wrote per ray
@@ -443,7 +451,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
                 RT_STAT(1, 1);
                 if (COOP) merge_in();
                 RT_MARK(sp, 7);
-                const NodeGroup *gp = &tv.groups[lane_get(lvloff, l) + g];
+                const NodeGroup *gp = &groups[lane_get(lvloff, l) + g];
                 uint32_t key[4], n_pass = 0, lb = 0, tmask = 0;
                 // One child: `test` fills the two rays' verdicts and entry parameters and says
                 // whether the box is dead (lo = +inf, hi = -inf: padding, or a triangle
@@ -544,7 +552,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
             uint32_t node = g * kTreeArity + (uint32_t)j;
             if (l == 0) {
                 cost++;
-                test_triangle(A.tris, node, r, lanebits, j, sp);
+                test_triangle(tris, node, r, lanebits, j, sp);
                 if (COOP) merge_out();
             } else {
                 l--;
@@ -554,7 +562,7 @@ __device__ __forceinline__ void traverse(const TravArgs &A, uint32_t lvloff, Ray
         }
     } else {
         for (uint32_t node = 0; node < (uint32_t)tv.n_groups0 * kTreeArity; node++)
-            test_triangle(A.tris, node, r, 0xffffffffu, 0, sp);
+            test_triangle(tris, node, r, 0xffffffffu, 0, sp);
     }
     RT_MARK(sp, 7);
     if (COOP) {
@@ -1819,7 +1827,7 @@ struct PrimaryTrace {
     float t[2];
 };
 
-template <bool CULL>
+template <bool CULL, bool OWN_BASES>
 __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv &env, uint32_t lane,
                                               uint32_t pix[2], uint32_t ctr[2], bool live[2],
                                               PrimaryTrace &o, uint32_t &cost, uint32_t *st, Stamps &sp)
@@ -1848,7 +1856,7 @@ __device__ __forceinline__ void trace_primary(const BatchArgs &A, const ChunkEnv
     st[4 * kBlock] = (live[0] ? 1u : 0u) | (live[1] ? 2u : 0u);
     asm volatile("" ::: "memory");
     RT_MARK(sp, 17);
-    traverse<CULL, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
+    traverse<CULL, false, true, false, OWN_BASES>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
     asm volatile("" ::: "memory");
     pix[0] = st[0 * kBlock]; pix[1] = st[1 * kBlock];
     ctr[0] = st[2 * kBlock]; ctr[1] = st[3 * kBlock];
@@ -1960,7 +1968,7 @@ enum : int {
     kDkWords = 32
 };
 
-template <bool CULL>
+template <bool CULL, bool OWN_BASES>
 __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
                                            uint32_t only_px, uint32_t lane, uint32_t *col, uint32_t *dk,
                                            uint32_t *__restrict__ work, uint32_t &ticket, Stamps &sp)
@@ -2059,7 +2067,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
         // rows 5-8 of every lane's column (the pixels' bookkeeping) survive this: trace_primary parks in rows 0-4
         PrimaryTrace o;
-        trace_primary<CULL>(A, env, lane, tp, ctr, live, o, cost, tmp, sp);
+        trace_primary<CULL, OWN_BASES>(A, env, lane, tp, ctr, live, o, cost, tmp, sp);
         uint32_t ln = lane;
         asm volatile("" : "+v"(ln));                         // lane-derived values are recomputed, not kept across the traversal
         if (mode < 2) {
@@ -2247,7 +2255,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
         asm volatile("" ::: "memory");
         RT_MARK(sp, 4);
-        traverse<CULL, false, false>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
+        traverse<CULL, false, false, false, OWN_BASES>(A.T, env.lvloff, w, lane, 0u, nullptr, cost, sp);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -2410,36 +2418,39 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
 
 // Before every k_batch launch: the previous launch's per-unit flags as lists.  Band y (units [y * band_units,
 // (y + 1) * band_units), band_units a multiple of 64) gets its ordinary units -- flag 0 -- in `norm`, the units kept
-// for last -- flag 3 -- go to `late`; listed and early units have their lists already.  A block takes 2048 units,
-// a wave 64 at a time (one band), and appends with one atomic per wave and class; order inside a list is by
-// arrival, which keeps neighbours together in runs of 64 -- what the bands' locality needs.  k_batch itself
-// cannot build these: a third of an image's units are "late", and a list appended to by every one of them goes
-// through ONE counter (measured: 460 us per unit instead of 20).
-constexpr uint32_t kClassifyPerBlock = 2048;
+// for last -- flag 3 -- go to `late`; listed and early units have their lists already.  A wave takes 64 units (one
+// band) and appends with one atomic per class; order inside a list is by arrival, which keeps neighbours
+// together in runs of 64 -- what the bands' locality needs.  k_batch itself cannot build these: a third of an
+// image's units are "late", and a list appended to by every one of them goes through ONE counter (measured:
+// 460 us per unit instead of 20).  The list header was zeroed by the launch before (k_batch, `lists_next`); the
+// same pass zeroes the feedback set after the one this launch writes (n_slots flags and the counts).
 __global__ __launch_bounds__(256) void k_classify(const uint32_t *__restrict__ flags, uint32_t flags_valid, uint32_t n_units,
                                                    uint32_t band_units, uint32_t *__restrict__ norm, uint32_t *__restrict__ late,
-                                                   BatchLists *__restrict__ lists)
+                                                   BatchLists *__restrict__ lists, uint32_t *__restrict__ flag_z,
+                                                   FbCounts *__restrict__ cnt_z, uint32_t n_slots)
 {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t i = 0; i < kClassifyPerBlock / 256u; i++) {
-        const uint32_t u0 = blockIdx.x * kClassifyPerBlock + (i * 4u + wave) * 64u;      // wave-uniform
-        if (u0 >= n_units)
-            break;
-        const uint32_t u = u0 + lane;
-        const uint32_t f = u < n_units ? (flags_valid ? flags[u] : 0u) : 0xffu;
-        const unsigned long long m_n = __ballot(f == 0u), m_l = __ballot(f == 3u);
-        const uint32_t y = u0 / band_units;
-        uint32_t b_n = 0, b_l = 0;
-        if (lane == 0) {
-            if (m_n) b_n = atomicAdd(&lists->n_norm[y], (uint32_t)__popcll(m_n));
-            if (m_l) b_l = atomicAdd(&lists->n_late, (uint32_t)__popcll(m_l));
-        }
-        b_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_n);
-        b_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_l);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (f == 0u) norm[(size_t)y * band_units + b_n + (uint32_t)__popcll(m_n & below)] = u;
-        if (f == 3u) late[b_l + (uint32_t)__popcll(m_l & below)] = u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t u0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;                    // wave-uniform
+    const uint32_t u = u0 + lane;
+    if (flag_z && u < n_slots)
+        flag_z[u] = 0u;
+    if (cnt_z && blockIdx.x == 0 && threadIdx.x < sizeof(FbCounts) / sizeof(uint32_t))
+        ((uint32_t *)cnt_z)[threadIdx.x] = 0u;
+    if (u0 >= n_units)
+        return;
+    const uint32_t f = u < n_units ? (flags_valid ? flags[u] : 0u) : 0xffu;
+    const unsigned long long m_n = __ballot(f == 0u), m_l = __ballot(f == 3u);
+    const uint32_t y = u0 / band_units;
+    uint32_t b_n = 0, b_l = 0;
+    if (lane == 0) {
+        if (m_n) b_n = atomicAdd(&lists->n_norm[y], (uint32_t)__popcll(m_n));
+        if (m_l) b_l = atomicAdd(&lists->n_late, (uint32_t)__popcll(m_l));
     }
+    b_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_n);
+    b_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)b_l);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (f == 0u) norm[(size_t)y * band_units + b_n + (uint32_t)__popcll(m_n & below)] = u;
+    if (f == 3u) late[b_l + (uint32_t)__popcll(m_l & below)] = u;
 }
 
 // One kernel per batch and pixel range.  The grid is what is resident at once; waves draw units
@@ -2460,6 +2471,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
     env.feedback = false; env.heavy_cost = 0xffffffffu; env.mean_cost = 0u;
     if (blockIdx.x == 0 && threadIdx.x < (uint32_t)kWorkSlots)
         work_next[threadIdx.x] = 0u;                         // the next launch's dispensers (stream-ordered after us)
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(BatchLists) / sizeof(uint32_t))
+        ((uint32_t *)A.fb.lists_next)[threadIdx.x] = 0u;     // and its list header, for its k_classify
     Stamps sp;
 #ifdef RT_STAMPS
     sp.start();
@@ -2667,7 +2680,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         const unsigned long long cost_before = desk(kDkCostLo);
         const bool is_task = D.stage == -1 && idx < n_tasks;
 #endif
-        fused_unit<CULL>(A, env, unit, only_px, lane, col, dk, work, ticket, sp);
+        fused_unit<CULL, WAVES >= 5>(A, env, unit, only_px, lane, col, dk, work, ticket, sp);
         if (prio)
             __builtin_amdgcn_s_setprio(0);
 #ifdef RT_STAMPS
@@ -3091,9 +3104,9 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
     A.band_units = batch_band_units(units);
     A.draw_early_ok = knobs.draw_early != 0;
     // the previous launch's flags as this launch's lists (stream-ordered: that launch is over, this one not begun)
-    (void)hipMemsetAsync(A.fb.lists_w, 0, sizeof(BatchLists), s);
-    k_classify<<<(units + kClassifyPerBlock - 1u) / kClassifyPerBlock, 256, 0, s>>>(A.fb.flag_r, A.fb.flags_valid, units, A.band_units,
-                                                                                  A.fb.norm_w, A.fb.late_w, A.fb.lists_w);
+    const uint32_t n_cls = std::max(units, A.fb.flag_z ? A.fb.n_slots : 0u);
+    k_classify<<<(n_cls + 255u) / 256u, 256, 0, s>>>(A.fb.flag_r, A.fb.flags_valid, units, A.band_units, A.fb.norm_w, A.fb.late_w,
+                                                      A.fb.lists_w, A.fb.flag_z, A.fb.cnt_z, A.fb.n_slots);
     // the batch kernels run with culling only (rt_render)
     if (waves == 5) k_batch<true, 5><<<g, kBlock, 0, s>>>(A, work, work_next);
     else            k_batch<true, 4><<<g, kBlock, 0, s>>>(A, work, work_next);

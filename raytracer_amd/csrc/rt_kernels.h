@@ -148,7 +148,8 @@ struct Knobs {
     int heavy_x4 = 0;            // RT_HEAVY_X4: cooperative form from this many quarters of the mean chunk cost on (0: chosen per launch)
     int general_regen = -1;      // RT_GENERAL_REGEN: 0 / 1 force path regeneration of the general kernel off / on
     int general_waves = 0;       // RT_GENERAL_WAVES: 1 / 2 force the build of the general kernel
-    int units_per_block = 96;    // RT_UNITS_PER_BLOCK: grid sizing of k_batch
+    int units_per_block = 16;    // RT_UNITS_PER_BLOCK: grid sizing of k_batch (96 left small launches on a fraction of the chip: an eighth of
+                                 // C3, 8 samples 0.96 -> 0.75 ms, 1 sample 1.2 -> 0.43; 4 is no better; large launches fill the chip either way)
     int batch_waves = 0;         // RT_BATCH_WAVES: 4 / 5 force the build of k_batch
     int intersect_lane = 2;      // RT_INTERSECT_LANE: 0 wave-wide, 1 per lane, 2 per chunk (rt_scene_hit)
     int task_prio = 1;           // RT_TASK_PRIO=0: listed pixel tasks of k_batch at ordinary wave priority

@@ -101,6 +101,25 @@ extern "C" void rt_debug_log(void *out, unsigned p0, unsigned n)
 }
 #endif
 
+#ifdef RT_TICKWAIT
+// Diagnostic build (tools/build_variant.sh tick -DRT_TICKWAIT, tools/tick_report.py): how long k_batch's waves wait for
+// dispenser tickets.  Summed over the waves of all launches since the last reset, in s_memtime ticks:
+// 0 wave lifetime, 1 wait for tickets drawn one unit ahead, 2 wait for tickets drawn on the spot (a stage or band
+// change), 3 / 4 their numbers, 5 time in pick(), 6 calls of pick().
+__device__ unsigned long long g_tick[8];
+extern "C" void rt_debug_tick(unsigned long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tick), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_tick), z, sizeof(z));
+    }
+}
+#define RT_TICK(x) x
+#else
+#define RT_TICK(x)
+#endif
 #ifdef RT_STAMPS
 // Diagnostic build only (tools/build_stamps.sh): where a wave's cycles go.  s_memtime stamps
 // around the segments of the batch kernels, summed over all waves into g_stamps[kernel][segment]
@@ -1965,6 +1984,7 @@ enum : int {
     kDkInBand,                       // the unit's cost counts for its band's sum
     kDkBandCostLo, kDkBandCostHi, kDkCostLo, kDkCostHi,
     kDkHeavy, kDkEarly, kDkLate,     // the launch's cost thresholds (feedback)
+    kDkTick1, kDkTick2, kDkTickN1, kDkTickN2, kDkTickP, kDkTickNP,   // RT_TICKWAIT only
     kDkWords = 32
 };
 
@@ -2579,12 +2599,14 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         return (klo | khi) ? (int)(klo & 7u) : -1;
     };
     uint32_t ticket = 0;
+    RT_TICK(const unsigned long long tick_begin = __builtin_amdgcn_s_memtime());
     {
         const uint32_t n_lists = (n_listed << px_log2) + n_early;
         Disp D = {};
         D.band = xcd;
         dk[kDkBandCostLo] = 0u; dk[kDkBandCostHi] = 0u; dk[kDkCostLo] = 0u; dk[kDkCostHi] = 0u;
         dk[kDkHeavy] = heavy_cost; dk[kDkEarly] = early_cost; dk[kDkLate] = late_cost;
+        RT_TICK(dk[kDkTick1] = 0u; dk[kDkTick2] = 0u; dk[kDkTickN1] = 0u; dk[kDkTickN2] = 0u; dk[kDkTickP] = 0u; dk[kDkTickNP] = 0u);
         D.stage = wave_id < n_lists ? -1 : 0;
         if (D.stage == -1) {
             enter_list(D, n_lists);
@@ -2608,6 +2630,16 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         const uint32_t n_tasks = n_tasks_of();
         if (D.k >= D.grab || D.d * D.grab + D.k >= D.nun) {  // this ticket is used up: the one drawn meanwhile
             D.k = 0;
+#ifdef RT_TICKWAIT
+            {
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                asm volatile("" ::: "memory");
+                uint32_t tk = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
+                asm volatile("" : "+s"(tk));
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                if (D.size) { dk[kDkTick1] = desk(kDkTick1) + (uint32_t)(t1 - t0); dk[kDkTickN1] = desk(kDkTickN1) + 1u; }
+            }
+#endif
             D.d = D.size ? (uint32_t)__builtin_amdgcn_readfirstlane(ticket) + D.bias : 0u;
             if (D.stage == -1)
                 D.bias = min(n_waves, D.size);               // every later ticket of the lists is a drawn one
@@ -2623,7 +2655,9 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
                     }
                     enter_late(D, (xcd + D.late_helped) & 7u);
                 } else {
+                    RT_TICK(const unsigned long long tp0 = __builtin_amdgcn_s_memtime());
                     const int y = A.band_help ? pick() : ++D.helped < 8u ? (int)((xcd + D.helped) & 7u) : -1;
+                    RT_TICK(dk[kDkTickP] = desk(kDkTickP) + (uint32_t)(__builtin_amdgcn_s_memtime() - tp0); dk[kDkTickNP] = desk(kDkTickNP) + 1u);
                     if (y >= 0) {
                         D.stage = 1;
                         enter_band(D, (uint32_t)y);
@@ -2634,9 +2668,11 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
                 }
                 D.d = D.size;
                 if (D.size) {
+                    RT_TICK(const unsigned long long ts0 = __builtin_amdgcn_s_memtime());
                     if (lane == 0)
                         ticket = atomicAdd(&work[D.ctr], 1u);
                     D.d = (uint32_t)__builtin_amdgcn_readfirstlane(ticket);
+                    RT_TICK(asm volatile("" : "+s"(D.d)); dk[kDkTick2] = desk(kDkTick2) + (uint32_t)(__builtin_amdgcn_s_memtime() - ts0); dk[kDkTickN2] = desk(kDkTickN2) + 1u);
                 }
             }
             if (D.stage >= 8)
@@ -2695,6 +2731,14 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
 #endif
     }
     flush_band(desk(kDkBand));
+#ifdef RT_TICKWAIT
+    if (lane == 0) {
+        atomicAdd(&g_tick[0], __builtin_amdgcn_s_memtime() - tick_begin);
+        atomicAdd(&g_tick[1], (unsigned long long)desk(kDkTick1)); atomicAdd(&g_tick[2], (unsigned long long)desk(kDkTick2));
+        atomicAdd(&g_tick[3], (unsigned long long)desk(kDkTickN1)); atomicAdd(&g_tick[4], (unsigned long long)desk(kDkTickN2));
+        atomicAdd(&g_tick[5], (unsigned long long)desk(kDkTickP)); atomicAdd(&g_tick[6], (unsigned long long)desk(kDkTickNP));
+    }
+#endif
     {
         const unsigned long long cost_sum = ((unsigned long long)desk(kDkCostHi) << 32) | desk(kDkCostLo);
         if (A.fb.cnt_w && lane == 0 && cost_sum)
@@ -3048,7 +3092,7 @@ static uint32_t batch_ss_log2(uint32_t n_samples)
     return l;
 }
 
-// Blocks of a launch over `units` wave-sized units: at least kUnitsPerBlock / 4 units per wave, at
+// Blocks of a launch over `units` wave-sized units: at least units_per_block / 4 units per wave, at
 // most the resident capacity.  (RT_UNITS_PER_BLOCK overrides, for tuning.)
 static uint32_t batch_grid(uint32_t units, uint32_t cap, const Knobs &knobs)
 {

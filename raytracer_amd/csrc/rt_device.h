@@ -280,21 +280,45 @@ __device__ __forceinline__ void tri_test_pair(const TriRec &T, RayPair &r, bool 
     cy = cy & !((q1.y > T.qmax) | (q2.y > T.qmax) | (q3.y > T.qmax));
     if (!(cx | cy))
         return;
+    // The area test of :113 compares a sum of three correctly rounded square roots with 0.001.  Its verdict is
+    // almost never close: inside the triangle the sum equals S up to rounding, outside it exceeds S by twice the
+    // area the point adds.  So the hardware square root (v_sqrt_f32, 1 ulp, a sixth of the correctly rounded
+    // expansion's issue time) decides whenever its answer is further from 0.001 than every way the two computations
+    // can differ -- 1.5 ulp per root and one rounding per addition, bounded by 16 * 2^-23 (s1 + s2 + s3 + S), plus a
+    // floor for roots of denormal squares the instruction may flush -- and only the remaining pairs take the
+    // reference's arithmetic.  NaN and infinity compare false on both sure sides and take it too.  Same verdicts.
+    bool ax_ = false, ay_ = false, ux = false, uy = false;                        // accepted / undecided, per ray
     if (cx) {
-        float s1 = sqrtf(q1.x), s2 = sqrtf(q2.x), s3 = sqrtf(q3.x);
-        if (!(fabsf(s1 + s2 + s3 - T.S) > 0.001f)) {                           // :113
-            r.best.x = t.x;
-            r.bestp.x = t.x * kBestInfl;
-            r.idx = T.orig;
-        }
+        const float s1 = __builtin_amdgcn_sqrtf(q1.x), s2 = __builtin_amdgcn_sqrtf(q2.x), s3 = __builtin_amdgcn_sqrtf(q3.x);
+        const float sum = s1 + s2 + s3, df = fabsf(sum - T.S), m = (sum + T.S) * 1.9073486e-6f + 1e-12f;
+        ax_ = df < 0.001f - m;
+        ux = !ax_ & !(df > 0.001f + m);
     }
     if (cy) {
-        float s1 = sqrtf(q1.y), s2 = sqrtf(q2.y), s3 = sqrtf(q3.y);
-        if (!(fabsf(s1 + s2 + s3 - T.S) > 0.001f)) {
-            r.best.y = t.y;
-            r.bestp.y = t.y * kBestInfl;
-            r.idy = T.orig;
+        const float s1 = __builtin_amdgcn_sqrtf(q1.y), s2 = __builtin_amdgcn_sqrtf(q2.y), s3 = __builtin_amdgcn_sqrtf(q3.y);
+        const float sum = s1 + s2 + s3, df = fabsf(sum - T.S), m = (sum + T.S) * 1.9073486e-6f + 1e-12f;
+        ay_ = df < 0.001f - m;
+        uy = !ay_ & !(df > 0.001f + m);
+    }
+    if (ux | uy) {
+        if (ux) {
+            float s1 = sqrtf(q1.x), s2 = sqrtf(q2.x), s3 = sqrtf(q3.x);
+            ax_ = !(fabsf(s1 + s2 + s3 - T.S) > 0.001f);                          // :113
         }
+        if (uy) {
+            float s1 = sqrtf(q1.y), s2 = sqrtf(q2.y), s3 = sqrtf(q3.y);
+            ay_ = !(fabsf(s1 + s2 + s3 - T.S) > 0.001f);
+        }
+    }
+    if (ax_) {
+        r.best.x = t.x;
+        r.bestp.x = t.x * kBestInfl;
+        r.idx = T.orig;
+    }
+    if (ay_) {
+        r.best.y = t.y;
+        r.bestp.y = t.y * kBestInfl;
+        r.idy = T.orig;
     }
 }
 

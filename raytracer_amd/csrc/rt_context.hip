@@ -77,6 +77,9 @@ struct Lane {
     FbCounts *cnt = nullptr;             // [3]
     uint32_t fb_slots = 0;
     uint32_t fb_seq = 0;                 // path launches so far (set rotation)
+    BounceJob *bjobs = nullptr;          // bounce queue (rt_kernels.h BounceQueue): one entry per pixel of the range
+    uint32_t *bq_ctr = nullptr;          // two pairs of counters, alternating by launch
+    uint32_t bq_cap = 0, bq_seq = 0;
     // unit-order feedback of k_batch (rt_kernels.h BatchFeedback): three sets rotating by launch
     uint32_t *bheavy[3] = {nullptr, nullptr, nullptr};
     uint32_t *bearly[3] = {nullptr, nullptr, nullptr};
@@ -234,6 +237,11 @@ int alloc_feedback(rt_context *c, Lane &L)
     RT_HIP(c, hipMemset(L.cnt, 0, 3 * sizeof(FbCounts)));
     L.fb_slots = (uint32_t)std::max<size_t>(chunks, 1);
     L.fb_seq = 0;
+    if ((rc = dalloc(c, c->part_allocs, L.bjobs, (size_t)(L.hi - L.lo) + 1))) return rc;
+    if ((rc = dalloc(c, c->part_allocs, L.bq_ctr, 4))) return rc;
+    RT_HIP(c, hipMemset(L.bq_ctr, 0, 4 * sizeof(uint32_t)));
+    L.bq_cap = L.hi - L.lo;
+    L.bq_seq = 0;
     // k_batch: one entry per unit of the smallest shape (2 pixels x 64 samples)
     // (lane 0 may be given the whole partition: rt_render)
     const size_t units = ((size_t)(&L == &c->lanes[0] ? c->n_local : L.hi - L.lo) + 1) / 2 + 1;
@@ -384,9 +392,13 @@ void timed_path(rt_context *c, Lane &L, const DevView &v, int max_depth, uint32_
         e1 = next_event(c);
     }
     ChunkFeedback f = next_feedback(L);
+    BounceQueue bq{};
+    bq.jobs = L.bjobs; bq.cap = L.bq_cap;
+    bq.ctr = L.bq_ctr + 2u * (L.bq_seq & 1u); bq.ctr_next = L.bq_ctr + 2u * ((L.bq_seq + 1u) & 1u);
     if (e0) (void)hipEventRecord(e0, L.stream);
-    launch_path(L.stream, v, L.lo, L.hi - L.lo, max_depth, c->max_blocks, L.ctl,
-                L.ctl->work[L.seq & 1u], L.ctl->work[(L.seq + 1u) & 1u], &f, n_samples, c->knobs);
+    if (launch_path(L.stream, v, L.lo, L.hi - L.lo, max_depth, c->max_blocks, L.ctl,
+                    L.ctl->work[L.seq & 1u], L.ctl->work[(L.seq + 1u) & 1u], &f, n_samples, c->knobs, &bq))
+        L.bq_seq++;
     L.seq++;
     if (e1) (void)hipEventRecord(e1, L.stream);
     c->launches++;

@@ -110,6 +110,25 @@ struct BatchFeedback {
     uint32_t flags_valid;                // 1: flag_r was written by a launch of this shape; 0: every unit is ordinary
 };
 
+// Bounce queue (rt_render with max_depth > 0 over a deep tree).  A sample is two launches: k_path's EMIT build
+// carries every pixel through its camera ray, direct light and BRDF sample -- coherent rays, wave-wide
+// traversal -- and appends a job per path that goes on; k_bounce's persistent waves then take jobs lane by lane,
+// walk the tree per lane, and a lane whose path has ended takes the next job at once.
+struct BounceJob {                   // 64 bytes
+    float o[3], d[3];                // the ray leaving the first hit (PathTracer.cu:80)
+    float beta[3], res[3];           // throughput and radiance so far (PathTracer.cu:73,79)
+    uint32_t draw;                   // next Philox draw of the pixel's stream
+    uint32_t p;                      // local pixel
+    uint32_t pad[2];
+};
+struct BounceQueue {
+    BounceJob *jobs;                 // nullptr: no queue (the one-kernel path)
+    uint32_t *ctr;                   // [0] jobs appended (k_path), [1] jobs handed out (k_bounce)
+    uint32_t *ctr_next;              // the other pair: zeroed by k_path for the next sample
+    uint32_t cap;                    // entries of jobs (>= pixels of the range)
+    int pairs;                       // k_bounce: a lane carries two paths (else one: half the walk per traversal)
+};
+
 struct DevView {
     int width, height;
     int cnt;                        // 1-based sample index (*cnt of kernel.cu:52-66)
@@ -145,6 +164,9 @@ struct DevView {
 struct Knobs {
     int lane_traversal = 1;      // RT_LANE_TRAVERSAL=0: bounce rays through the wave-wide traversal
     int bounce_waves = 3;        // RT_BOUNCE_WAVES=2: the two-wave build of the bounce kernel
+    int bounce_pairs = 0;        // RT_BOUNCE_PAIRS=1: k_bounce's lanes carry two paths each
+    int bounce_queue = 0;        // RT_BOUNCE_QUEUE=1: bounces over a deep tree as k_path<.., EMIT> + k_bounce (bit-identical; measured slower
+                                 // than k_path carrying every path to its end: C3 depth 12 3.5 against 2.9 ms per sample)
     int heavy_x4 = 0;            // RT_HEAVY_X4: cooperative form from this many quarters of the mean chunk cost on (0: chosen per launch)
     int general_regen = -1;      // RT_GENERAL_REGEN: 0 / 1 force path regeneration of the general kernel off / on
     int general_waves = 0;       // RT_GENERAL_WAVES: 1 / 2 force the build of the general kernel
@@ -170,9 +192,10 @@ Knobs read_knobs();
 // n_samples > 1: every chunk renders that many consecutive samples (v.cnt, v.cnt + 1, ..) in this one
 // launch -- only where path_renders_runs(v) says so (shallow trees or the scan, no general scene);
 // elsewhere the caller launches once per sample.
-void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
+// -> true if the launch took the bounce queue (its counter pair is then used up: the caller alternates)
+bool launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                 const ChunkFeedback *fb, uint32_t n_samples, const Knobs &knobs);
+                 const ChunkFeedback *fb, uint32_t n_samples, const Knobs &knobs, const BounceQueue *bq = nullptr);
 bool path_renders_runs(const DevView &v);
 constexpr uint32_t kPathChunk = 128;   // pixels per chunk of the path kernel (two per lane)
 

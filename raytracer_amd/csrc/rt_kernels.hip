@@ -755,6 +755,7 @@ struct PathArgs {
     bool regen;                      // general kernel: dead slots take new pixels at once (see general_wave)
     uint32_t n_samples;              // k_path: progressive samples cnt, cnt + 1, .. a chunk renders in this launch
     bool lane_traversal;             // k_path: bounce rays walk the tree lane by lane (traverse_lane)
+    BounceQueue bq;                  // k_path<.., EMIT>, k_bounce
 };
 // Per-launch values every chunk shares (kept apart from the kernel argument block, which
 // stays read-only in the constant address space).
@@ -858,7 +859,7 @@ struct RayState {
 #else
 #define RT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-template <bool CULL, bool COOP, bool DEPTH0>
+template <bool CULL, bool COOP, bool DEPTH0, bool EMIT = false>
 __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &env, uint32_t chunk,
                                            uint32_t lane, uint32_t wib,
                                            unsigned long long *s_best, uint32_t *s_cost, float *st,
@@ -878,6 +879,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
 
     auto pixel_of = [&](int h) { return A.p0 + min(chunk * kPathChunk + (uint32_t)h * 64u + lane, A.n - 1u); };
     bool mine[2], alive[2], ishit[2] = {false, false}, cast[2] = {false, false};
+    bool emitted[2] = {false, false};        // EMIT: the path goes on in k_bounce, which writes its pixel's counter
     State S[2];
     const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
     RayPair w;
@@ -915,7 +917,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
         // order and keep them as a mask -- cheaper bookkeeping per node group; C2 +1.9 %)
         // (and a third: rays a surface scattered, and the shadow rays cast where they land, walk the tree
         // lane by lane -- see traverse_lane; in the cooperative form every wave then does the same work)
-        if (!DEPTH0 && bounce > 0 && A.lane_traversal)
+        if (!DEPTH0 && !EMIT && bounce > 0 && A.lane_traversal)
             traverse_lane<CULL>(A.T, env.s_lvl, w, j < 0 ? alive[0] : cast[0], j < 0 ? alive[1] : cast[1], cost);
         else if (j >= 0 && A.occlusion)
             traverse<CULL, COOP, false>(A.T, env.lvloff, w, lane, wib, s_best, cost, sp0);
@@ -1063,6 +1065,34 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
             ishit[h] = false;
             RT_SCHED_FENCE();
         }
+        if (EMIT) {
+            // every path that goes on becomes a job of k_bounce (bounce is 0 here: the loop ends below)
+            const unsigned long long e0 = __ballot(alive[0]), e1 = __ballot(alive[1]);
+            if (e0 | e1) {
+                const uint32_t ne = (uint32_t)__popcll(e0) + (uint32_t)__popcll(e1);
+                uint32_t base = 0;
+                if (writer && lane == 0)
+                    base = atomicAdd(&A.bq.ctr[0], ne);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                n_bounce += ne;
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (!alive[h])
+                        continue;
+                    const uint32_t idx = base + (h ? (uint32_t)__popcll(e0) : 0u) + (uint32_t)__popcll((h ? e1 : e0) & below);
+                    if (writer && idx < A.bq.cap) {
+                        float4 *J = (float4 *)&A.bq.jobs[idx];
+                        J[0] = make_float4(ro[h].x, ro[h].y, ro[h].z, rd[h].x);
+                        J[1] = make_float4(rd[h].y, rd[h].z, S[h].beta.x, S[h].beta.y);
+                        J[2] = make_float4(S[h].beta.z, S[h].res.x, S[h].res.y, S[h].res.z);
+                        J[3] = make_float4(__uint_as_float(S[h].draw), __uint_as_float(pixel_of(h)), 0.0f, 0.0f);
+                    }
+                    emitted[h] = true;
+                    alive[h] = false;
+                }
+            }
+        }
         const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]);
         if (DEPTH0 || !(a0 | a1))
             break;
@@ -1075,7 +1105,7 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
     if (writer) {
 #pragma unroll
         for (int h = 0; h < 2; h++)
-            if (mine[h])
+            if (mine[h] && !emitted[h])
                 v.rng_ctr[pixel_of(h)] = S[h].draw;
     }
     if (COOP) {
@@ -1105,13 +1135,13 @@ __device__ __forceinline__ void path_chunk(const PathArgs &A, const ChunkEnv &en
 // read what wave 0 wrote) keep n_samples = 1; shallow ones (C1, C2) render a whole rt_render call in
 // one launch -- no launch gaps and no tail per sample, which is most of a sample's time on a small
 // partition.  The chunk's feedback is recorded once, with the run's summed cost.
-template <bool CULL, bool COOP, bool DEPTH0>
+template <bool CULL, bool COOP, bool DEPTH0, bool EMIT = false>
 __device__ __forceinline__ void path_run(const PathArgs &A, const ChunkEnv &env, uint32_t chunk, uint32_t lane,
                                          uint32_t wib, unsigned long long *s_best, uint32_t *s_cost, float *st)
 {
     uint32_t cost = 0;
     for (uint32_t s = 0; s < A.n_samples; s++)
-        path_chunk<CULL, COOP, DEPTH0>(A, env, chunk, lane, wib, s_best, s_cost, st, A.v.cnt + (int)s, cost);
+        path_chunk<CULL, COOP, DEPTH0, EMIT>(A, env, chunk, lane, wib, s_best, s_cost, st, A.v.cnt + (int)s, cost);
     if (lane == 0 && (!COOP || wib == 0) && env.feedback)
         record_cost(A.fb, env, chunk, cost);
 }
@@ -1715,7 +1745,7 @@ __device__ __forceinline__ void run_chunks(uint32_t n_chunks, const ChunkFeedbac
     }
 }
 
-template <bool CULL, bool DEPTH0, int WAVES>
+template <bool CULL, bool DEPTH0, int WAVES, bool EMIT = false>
 __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32_t *__restrict__ work,
                                                  uint32_t *__restrict__ work_next, int dynamic)
 {
@@ -1734,10 +1764,219 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path(const PathArgs A, uint32
             s_lvl[threadIdx.x] = A.T.tv.level_off[threadIdx.x];
         __syncthreads();
     }
+    if (EMIT && blockIdx.x == 0 && threadIdx.x < 2u)
+        A.bq.ctr_next[threadIdx.x] = 0u;                     // the next sample's counters (stream-ordered after us and our k_bounce)
     run_chunks<CULL>(
         n_chunks, A.fb, A.heavy_x4, work, work_next, dynamic, env, &s_chunk,
-        [&](uint32_t chunk) { path_run<CULL, false, DEPTH0>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
-        [&](uint32_t chunk) { path_run<CULL, true, DEPTH0>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+        [&](uint32_t chunk) { path_run<CULL, false, DEPTH0, EMIT>(A, env, chunk, lane, wib, nullptr, nullptr, st); },
+        [&](uint32_t chunk) { path_run<CULL, true, DEPTH0, EMIT>(A, env, chunk, lane, wib, s_best, &s_cost, st); });
+}
+
+// The paths k_path<.., EMIT> handed on, from their first bounce ray to their end (PathTracer.cu:22-88 from the second
+// iteration on).  Scattered rays share nothing, so everything here is per lane: the traversal (traverse_lane), the
+// bounce a lane is at, and its end -- a lane (two slots each) whose path is over takes the next job of the queue at
+// the next bounce boundary, so the waves stay full however differently the paths end (in the one-kernel form a
+// wave carried its 128 pixels until the last of them had ended: at the third bounce one slot in seven was alive).
+// Same arithmetic, same order per path as path_chunk; the pixel's running mean and counter are written at the
+// path's end, once.
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 3) void k_bounce(const PathArgs A)
+{
+    using State = RayState<false>;
+    __shared__ float s_stash[2 * State::kSlots][kBlock];
+    __shared__ uint32_t s_lvl[kMaxLevels];
+    float *st = &s_stash[0][threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < (uint32_t)kMaxLevels)
+        s_lvl[threadIdx.x] = A.T.tv.level_off[threadIdx.x];
+    __syncthreads();
+    const DevView &v = A.v;
+    const int L = v.n_lights;
+    const float E = A.T.tv.extent;
+    const uint32_t n_jobs = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.bq.ctr[0]), A.bq.cap);
+    const float inf2[2] = {kInf, kInf}, none2[2] = {-1.0f, -1.0f};
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t cost = 0, n_shadow = 0, n_bounce = 0;
+    bool alive[2] = {false, false}, more_jobs = n_jobs != 0u;
+    uint32_t pl[2] = {0u, 0u};
+    int bnc[2] = {0, 0};
+    State S[2];
+    S[0] = State{}; S[1] = State{};
+    v3 ro[2] = {mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)}, rd[2] = {mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)};
+    RayPair w;
+    for (;;) {
+        // ---- free slots take jobs
+        const unsigned long long d0 = __ballot(!alive[0]), d1 = A.bq.pairs ? __ballot(!alive[1]) : 0ull;
+        if (more_jobs && (d0 | d1)) {
+            const uint32_t nd = (uint32_t)__popcll(d0) + (uint32_t)__popcll(d1);
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&A.bq.ctr[1], nd);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + nd >= n_jobs)
+                more_jobs = false;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t idx = base + (h ? (uint32_t)__popcll(d0) : 0u) + (uint32_t)__popcll((h ? d1 : d0) & below);
+                if (!alive[h] && (h == 0 || A.bq.pairs) && idx < n_jobs) {
+                    const float4 *J = (const float4 *)&A.bq.jobs[idx];
+                    const float4 j0 = J[0], j1 = J[1], j2 = J[2], j3 = J[3];
+                    ro[h] = mk3(j0.x, j0.y, j0.z); rd[h] = mk3(j0.w, j1.x, j1.y);
+                    S[h].beta = mk3(j1.z, j1.w, j2.x); S[h].res = mk3(j2.y, j2.z, j2.w);
+                    S[h].draw = __float_as_uint(j3.x);
+                    pl[h] = __float_as_uint(j3.y);
+                    bnc[h] = 1;
+                    alive[h] = true;
+                }
+            }
+        }
+        if (!__ballot(alive[0] | alive[1]))
+            break;
+        // ---- closest hit of this bounce: PathTracer.cu:27-64
+        pair_set(w, ro, rd, inf2, none2, alive, E);
+        S[0].save(st);
+        S[1].save(st + State::kSlots * kBlock);
+        asm volatile("" ::: "memory");
+        traverse_lane<CULL>(A.T, s_lvl, w, alive[0], alive[1], cost);
+        asm volatile("" ::: "memory");
+        S[0].load(st);
+        S[1].load(st + State::kSlots * kBlock);
+        bool ishit[2], cast[2] = {false, false};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float t = h ? w.best.y : w.best.x;
+            const int32_t id = h ? w.idy : w.idx;
+            ishit[h] = alive[h] && scene_ishit(t) && id >= 0;
+            S[h].le = mk3(0.0f, 0.0f, 0.0f);
+            if (alive[h]) {
+                // draws of this bounce: tmp (PathTracer.cu:27) + one per light (Scene.cu:87)
+                S[h].draw += 1u + (ishit[h] ? (uint32_t)L : 0u);
+                if (!ishit[h]) {                             // PathTracer.cu:64 -> return res
+                    finalize_path(v, pl[h], S[h].res, v.cnt);
+                    v.rng_ctr[pl[h]] = S[h].draw;
+                    alive[h] = false;
+                }
+            }
+            if (ishit[h]) {
+                Ray r;
+                r.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+                r.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+                Hit H;
+                fill_hit(v, r, id, H);
+                S[h].pos = H.pos; S[h].normal = H.normal; S[h].tangent = H.tangent;
+                S[h].model = H.model;
+                S[h].wo_y = local_y(H, neg(r.d));            // Object.cu:107-110 on wo = -r.dir
+            }
+            RT_SCHED_FENCE();
+        }
+        // ---- the lights, in order: Scene.cu:84-122, shadow rays Scene.cu:225-241
+        if (__ballot(ishit[0] | ishit[1])) {
+            for (int j = 0; j < L; j++) {
+                const LightRec light = load_uniform(&v.lights[j]);
+                v3 so[2], sd[2];
+                float sb[2], ss[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    cast[h] = false;
+                    so[h] = mk3(0.0f, 0.0f, 0.0f); sd[h] = mk3(0.0f, 0.0f, 0.0f);
+                    sb[h] = kInf; ss[h] = -1.0f;
+                    if (ishit[h]) {
+                        LightSample s = sample_point_light(S[h].hit(), v.models[S[h].model], S[h].wo_y, light);
+                        cast[h] = s.cast;
+                        so[h] = s.sr.o; sd[h] = s.sr.d;
+                        S[h].thr = fmaxf(s.thr, 0.0f);
+                        S[h].contrib = s.contrib;
+                        if (A.occlusion) {
+                            float m = 1e-4f * (fabsf(S[h].thr) + fabsf(so[h].x) + fabsf(so[h].y) + fabsf(so[h].z)) + 1e-6f;
+                            sb[h] = fminf(kInf, S[h].thr + m);
+                            ss[h] = S[h].thr - m;
+                        }
+                    }
+                    RT_SCHED_FENCE();
+                }
+                const unsigned long long c0 = __ballot(cast[0]), c1 = __ballot(cast[1]);
+                if (!(c0 | c1))
+                    continue;
+                n_shadow += (uint32_t)__popcll(c0) + (uint32_t)__popcll(c1);
+                pair_set(w, so, sd, sb, ss, cast, E);
+                S[0].save(st);
+                S[1].save(st + State::kSlots * kBlock);
+                asm volatile("" ::: "memory");
+                traverse_lane<CULL>(A.T, s_lvl, w, cast[0], cast[1], cost);
+                asm volatile("" ::: "memory");
+                S[0].load(st);
+                S[1].load(st + State::kSlots * kBlock);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (!cast[h])
+                        continue;
+                    const float best = h ? w.best.y : w.best.x;
+                    const int32_t sid = h ? w.idy : w.idx;
+                    bool blocked = false;
+                    if (scene_ishit(best) && sid >= 0) {
+                        Ray sr;
+                        sr.o = h ? mk3(w.ox.y, w.oy.y, w.oz.y) : mk3(w.ox.x, w.oy.x, w.oz.x);
+                        sr.d = h ? mk3(w.dx.y, w.dy.y, w.dz.y) : mk3(w.dx.x, w.dy.x, w.dz.x);
+                        v3 hp = sid < v.n_tris ? ray_pos(sr, best)
+                                               : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
+                        blocked = length(sub(hp, sr.o)) < S[h].thr;
+                    }
+                    if (!blocked)                            // res += ... in light order (Scene.cu:120)
+                        S[h].le = add(S[h].le, S[h].contrib);
+                }
+            }
+        }
+        // ---- end of the bounce: PathTracer.cu:73-88
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ro[h] = mk3(0.0f, 0.0f, 0.0f); rd[h] = mk3(0.0f, 0.0f, 0.0f);
+            if (!ishit[h])
+                continue;
+            const uint32_t p = pl[h];
+            S[h].res = add(S[h].res, mul(S[h].beta, S[h].le));           // PathTracer.cu:73
+            const ModelRec &M = v.models[S[h].model];
+            const Hit H = S[h].hit();
+            float u[4];
+            pixel_uniform4(v.pixmap[p], S[h].draw - 1u - (uint32_t)L, u);  // tmp of PathTracer.cu:27
+            v3 wi;
+            float pdf;
+            v3 f = rec_sample_f_y(H, M, S[h].wo_y, wi, pdf, u[0], u[1]);   // PathTracer.cu:76
+            bool done = (pdf < 0.0001f || len_below_1e4(f));             // PathTracer.cu:77
+            if (!done) {
+                S[h].beta = mul(S[h].beta, divs(scale(f, fabsf(dot(wi, H.normal))), pdf));   // :79
+                Ray nr = spawn_ray(H, wi);                               // :80
+                ro[h] = nr.o; rd[h] = nr.d;
+                if (bnc[h] > 3) {                                        // :82-88
+                    if (u[2] < 0.5f)
+                        done = true;
+                    else
+                        S[h].beta = divs(S[h].beta, 1.0f - 0.5f);
+                }
+            }
+            if (!done && bnc[h] + 1 > A.max_depth) {
+                // Next iteration: one draw (:27), a trace whose result nothing reads
+                // (Lambertian, no environment light), then the break of :64.
+                S[h].draw += 1u;
+                done = true;
+            }
+            if (done) {
+                finalize_path(v, p, S[h].res, v.cnt);
+                v.rng_ctr[p] = S[h].draw;
+                alive[h] = false;
+            } else {
+                bnc[h]++;
+                n_bounce++;
+            }
+            RT_SCHED_FENCE();
+        }
+    }
+    // (n_bounce is per lane here)
+    for (int o = 32; o > 0; o >>= 1)
+        n_bounce += (uint32_t)__shfl_xor((int)n_bounce, o);
+    if (lane == 0) {
+        if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+        if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
+    }
 }
 
 // WAVES per SIMD the register allocation aims at: 1 keeps the whole state in registers, 2 spills
@@ -2999,6 +3238,8 @@ Knobs read_knobs()
     auto geti = [](const char *name, int &dst) { if (const char *e = std::getenv(name)) dst = std::atoi(e); };
     geti("RT_LANE_TRAVERSAL", k.lane_traversal);
     geti("RT_BOUNCE_WAVES", k.bounce_waves);
+    geti("RT_BOUNCE_QUEUE", k.bounce_queue);
+    geti("RT_BOUNCE_PAIRS", k.bounce_pairs);
     geti("RT_HEAVY_X4", k.heavy_x4);
     geti("RT_GENERAL_REGEN", k.general_regen);
     geti("RT_GENERAL_WAVES", k.general_waves);
@@ -3020,12 +3261,12 @@ bool path_renders_runs(const DevView &v)
     return !v.general && !(v.cull && v.tree.top >= 3);
 }
 
-void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
+bool launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int max_depth,
                  int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
-                 const ChunkFeedback *fb, uint32_t n_samples, const Knobs &knobs)
+                 const ChunkFeedback *fb, uint32_t n_samples, const Knobs &knobs, const BounceQueue *bq)
 {
     if (n == 0)
-        return;
+        return false;
     PathArgs A{};
     A.v = v;
     A.T = trav_args(v);
@@ -3072,7 +3313,16 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         if (!v.cull)      k_path_general<false, 1><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else if (gw == 1) k_path_general<true, 1><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else              k_path_general<true, 2><<<ga, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        return;
+        return false;
+    }
+    if (v.cull && bounce3 && deep && A.lane_traversal && knobs.bounce_queue && bq && bq->jobs && bq->cap >= n) {
+        // bounces over a deep tree: camera rays, direct light and the BRDF sample in chunks (coherent rays), the
+        // rest of every path from a queue, lane by lane (k_bounce)
+        A.bq = *bq;
+        A.bq.pairs = knobs.bounce_pairs;
+        k_path<true, false, 3, true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
+        k_bounce<true><<<(uint32_t)std::max(max_blocks, 1) * 3u, kBlock, 0, s>>>(A);
+        return true;
     }
     if (v.cull) {
         if (bounce3)  k_path<true, false, 3><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
@@ -3082,6 +3332,7 @@ void launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         if (d0) k_path<false, true, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
         else    k_path<false, false, 2><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
     }
+    return false;
 }
 
 // Samples a wave holds: the smallest power of two that takes the whole batch (<= 64).

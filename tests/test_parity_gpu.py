@@ -939,7 +939,7 @@ def test_lane_traversal_equals_wave_traversal(gpu_ctx_factory, monkeypatch):
     cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
     for scene in (soup, scenes.material_test_scene()[0]):
         frames = []
-        for knobs in ({"RT_LANE_TRAVERSAL": "0"}, {}, {"RT_BOUNCE_WAVES": "2"}):
+        for knobs in ({"RT_LANE_TRAVERSAL": "0"}, {}, {"RT_BOUNCE_WAVES": "2"}, {"RT_BOUNCE_QUEUE": "1"}):
             for k, val in knobs.items():
                 monkeypatch.setenv(k, val)
             ctx = gpu_ctx_factory(96, 64)
@@ -959,6 +959,49 @@ def test_lane_traversal_equals_wave_traversal(gpu_ctx_factory, monkeypatch):
     ctx.set_camera(cam)
     ctx.render(3, 7)
     check_images(ctx.read_framebuffer(), ref)
+
+
+def test_bounce_queue_equals_one_kernel_form(gpu_ctx_factory, monkeypatch):
+    """Bounces over a deep tree as two launches per sample (RT_BOUNCE_QUEUE=1: k_path's EMIT build up to the BRDF
+    sample of the first hit, then k_bounce's persistent waves, which take the remaining paths from a queue lane by
+    lane, one or two paths per lane) or as one (the default: k_path carries every path to its end).  Same arithmetic per path, so the same bits, the
+    same ray counts and the same Philox counters (a second render call continues from them): a decimated C3
+    whole and as the union of three partitions, with few persistent blocks too, and against the oracle."""
+    cfg = scenes.c3(160, 96, lon=40, lat=30, ground=(8, 5))
+    spp, depth = 3, 12
+    frames, counts = [], []
+    for knobs in ({"RT_BOUNCE_QUEUE": "0"}, {"RT_BOUNCE_QUEUE": "1"}, {"RT_BOUNCE_QUEUE": "1", "RT_MAX_BLOCKS": "2"},
+                  {"RT_BOUNCE_QUEUE": "1", "RT_BOUNCE_PAIRS": "1"}):
+        for k, val in knobs.items():
+            monkeypatch.setenv(k, val)
+        ctx = gpu_ctx_factory(cfg.width, cfg.height)
+        ctx.upload_scene(cfg.scene)
+        ctx.set_camera(cfg.camera)
+        ctx.render(2, depth)
+        ctx.render(spp - 2, depth)                      # continues from the counters the first call left
+        frames.append(ctx.read_framebuffer())
+        st = ctx.stats()
+        counts.append((st.primary_rays, st.shadow_rays, st.bounce_rays))
+        for k in knobs:
+            monkeypatch.delenv(k)
+    assert counts[0][2] > 0
+    for other, cnt in zip(frames[1:], counts[1:]):
+        assert np.array_equal(frames[0]["rgba"].view(np.uint32), other["rgba"].view(np.uint32))
+        assert np.array_equal(frames[0]["prim_id"], other["prim_id"])
+        assert cnt == counts[0]
+    check_images(frames[1], orc.render(cfg.scene, cfg.camera, cfg.width, cfg.height, spp=spp, max_depth=depth))
+    # three ranks' partitions, gathered: the whole frame
+    union = np.zeros_like(frames[1]["rgba"])
+    monkeypatch.setenv("RT_BOUNCE_QUEUE", "1")
+    part = gpu_ctx_factory(cfg.width, cfg.height)
+    part.upload_scene(cfg.scene)
+    part.set_camera(cfg.camera)
+    for rank in range(3):
+        part.set_partition(rank, 3, 16)
+        part.render(spp, depth)
+        fb = part.read_framebuffer()
+        union += np.where((fb["prim_id"] != -2)[..., None], fb["rgba"], 0.0).astype(np.float32)
+    assert np.array_equal(union.view(np.uint32), frames[1]["rgba"].view(np.uint32))
 
 
 def test_general_kernel_with_few_persistent_waves(gpu_ctx_factory, monkeypatch):

@@ -2003,6 +2003,267 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_path_general(const PathArgs A
     general_wave<CULL>(A, env, work, n_chunks, lane);
 }
 
+// k_bounce as a per-lane STATE MACHINE (RT_BOUNCE_QUEUE=2).  In k_bounce every traversal call ends when its slowest
+// lane does, and walks of scattered rays differ by an order of magnitude in length: 11 % of the lanes are active on
+// average.  Here the loop's body is ONE step of a walk (a node group or a triangle record), for every lane that is
+// walking; a lane whose walk is over waits, and when a quarter of the wave's live lanes wait (or nobody walks) those
+// lanes alone go through what follows a walk -- the closest hit's record and the first light, a shadow ray's verdict
+// and the next light, the end of the bounce and the next ray, or the end of the path and the next job -- and start
+// their next walk.  One path per lane; its state is parked in the lane's LDS column while it walks.  Same device
+// functions and the same order per path as path_chunk (lights are read per lane here: lanes are at different ones).
+template <bool CULL>
+__global__ __launch_bounds__(kBlock, 3) void k_bounce_sm(const PathArgs A)
+{
+    using State = RayState<false>;
+    __shared__ float s_stash[State::kSlots][kBlock];
+    __shared__ uint32_t s_lvl[kMaxLevels];
+    float *st = &s_stash[0][threadIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x < (uint32_t)kMaxLevels)
+        s_lvl[threadIdx.x] = A.T.tv.level_off[threadIdx.x];
+    __syncthreads();
+    const DevView &v = A.v;
+    const TreeView &tv = A.T.tv;
+    const int L = v.n_lights;
+    const float E = tv.extent;
+    const uint32_t n_jobs = min((uint32_t)__builtin_amdgcn_readfirstlane((int)A.bq.ctr[0]), A.bq.cap);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t n_shadow = 0, n_bounce = 0;
+    bool alive = false, walking = false, fresh = false, more_jobs = n_jobs != 0u;
+    uint32_t pl = 0;
+    int bnc = 0, ph = -1;                                    // ph: -1 the walk is a closest hit, else the shadow ray towards light ph
+    int level = 0;
+    uint32_t g = 0;
+    unsigned long long pend = 0;
+    v3 jo = mk3(0.0f, 0.0f, 0.0f), jd = mk3(1.0f, 0.0f, 0.0f);   // a fresh job's ray
+    State S;
+    S = State{};
+    RayPair w;
+    {
+        const v3 z[2] = {jo, jo}, x[2] = {jd, jd};
+        const float b[2] = {0.0f, 0.0f}, sn[2] = {-1.0f, -1.0f};
+        const bool no[2] = {false, false};
+        pair_set(w, z, x, b, sn, no, E);
+    }
+    auto expand = [&](int lvl, uint32_t grp) -> uint32_t {
+        const float4 *G = (const float4 *)(tv.groups + s_lvl[lvl] + grp);
+        const float4 l0 = G[0], l1 = G[1], l2 = G[2], h0 = G[3], h1 = G[4], h2 = G[5];
+        uint32_t m = 0;
+        bool px, py;
+        float ex, ey;
+        node_test(w, l0.x, l1.x, l2.x, h0.x, h1.x, h2.x, px, py, ex, ey);
+        m |= ((px | py) & !(l0.x > h0.x)) ? 1u : 0u;
+        node_test(w, l0.y, l1.y, l2.y, h0.y, h1.y, h2.y, px, py, ex, ey);
+        m |= ((px | py) & !(l0.y > h0.y)) ? 2u : 0u;
+        node_test(w, l0.z, l1.z, l2.z, h0.z, h1.z, h2.z, px, py, ex, ey);
+        m |= ((px | py) & !(l0.z > h0.z)) ? 4u : 0u;
+        node_test(w, l0.w, l1.w, l2.w, h0.w, h1.w, h2.w, px, py, ex, ey);
+        m |= ((px | py) & !(l0.w > h0.w)) ? 8u : 0u;
+        return m;
+    };
+    for (;;) {
+        // ---- who can go on only through the code below?
+        const unsigned long long walk_m = __ballot(walking), live_m = __ballot(alive);
+        const unsigned long long ready_m = __ballot(!walking && (alive || more_jobs));
+        if (!(walk_m | ready_m))
+            break;
+        const uint32_t n_ready = (uint32_t)__popcll(ready_m);
+        if (n_ready && (!walk_m || 4u * n_ready >= (uint32_t)__popcll(live_m) + 4u)) {
+            // free lanes take jobs
+            const unsigned long long dead_m = __ballot(!alive);
+            if (more_jobs && dead_m) {
+                const uint32_t nd = (uint32_t)__popcll(dead_m);
+                uint32_t base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&A.bq.ctr[1], nd);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + nd >= n_jobs)
+                    more_jobs = false;
+                const uint32_t idx = base + (uint32_t)__popcll(dead_m & below);
+                if (!alive && idx < n_jobs) {
+                    const float4 *J = (const float4 *)&A.bq.jobs[idx];
+                    const float4 j0 = J[0], j1 = J[1], j2 = J[2], j3 = J[3];
+                    jo = mk3(j0.x, j0.y, j0.z); jd = mk3(j0.w, j1.x, j1.y);
+                    S = State{};
+                    S.beta = mk3(j1.z, j1.w, j2.x); S.res = mk3(j2.y, j2.z, j2.w);
+                    S.draw = __float_as_uint(j3.x);
+                    pl = __float_as_uint(j3.y);
+                    bnc = 1;
+                    alive = true;
+                    fresh = true;
+                    S.save(st);
+                }
+            }
+            if (!walking && alive) {
+                bool go = false;                             // a new walk starts: ray (no, nd), window (nb, ns)
+                v3 no = jo, nd = jd;
+                float nb = kInf, ns = -1.0f;
+                S.load(st);
+                if (fresh) {                                 // the job's own ray: closest hit of bounce 1
+                    fresh = false;
+                    ph = -1;
+                    go = true;
+                } else {
+                    after_triangles<false>(A.T, w);          // the quadrics (Scene.cu:31-37)
+                    if (ph < 0) {
+                        // ---- closest hit of this bounce: PathTracer.cu:27-64
+                        const float t = w.best.x;
+                        const int32_t id = w.idx;
+                        const bool ishit = scene_ishit(t) && id >= 0;
+                        S.le = mk3(0.0f, 0.0f, 0.0f);
+                        S.draw += 1u + (ishit ? (uint32_t)L : 0u);
+                        if (!ishit) {                        // PathTracer.cu:64 -> return res
+                            finalize_path(v, pl, S.res, v.cnt);
+                            v.rng_ctr[pl] = S.draw;
+                            alive = false;
+                        } else {
+                            Ray r;
+                            r.o = mk3(w.ox.x, w.oy.x, w.oz.x);
+                            r.d = mk3(w.dx.x, w.dy.x, w.dz.x);
+                            Hit H;
+                            fill_hit(v, r, id, H);
+                            S.pos = H.pos; S.normal = H.normal; S.tangent = H.tangent;
+                            S.model = H.model;
+                            S.wo_y = local_y(H, neg(r.d));
+                            ph = 0;
+                        }
+                    } else {
+                        // ---- verdict of the shadow ray towards light ph: Scene.cu:225-241
+                        const float best = w.best.x;
+                        const int32_t sid = w.idx;
+                        bool blocked = false;
+                        if (scene_ishit(best) && sid >= 0) {
+                            Ray sr;
+                            sr.o = mk3(w.ox.x, w.oy.x, w.oz.x);
+                            sr.d = mk3(w.dx.x, w.dy.x, w.dz.x);
+                            v3 hp = sid < v.n_tris ? ray_pos(sr, best)
+                                                   : hit_pos_sphere(v.spheres[sid - v.n_tris], sr, best);
+                            blocked = length(sub(hp, sr.o)) < S.thr;
+                        }
+                        if (!blocked)
+                            S.le = add(S.le, S.contrib);
+                        ph++;
+                    }
+                    if (alive) {
+                        // ---- the next light this path casts a shadow ray towards (Scene.cu:84-122)
+                        for (; ph < L; ph++) {
+                            const LightRec light = v.lights[ph];
+                            LightSample ls = sample_point_light(S.hit(), v.models[S.model], S.wo_y, light);
+                            S.thr = fmaxf(ls.thr, 0.0f);
+                            S.contrib = ls.contrib;
+                            if (ls.cast) {
+                                no = ls.sr.o; nd = ls.sr.d;
+                                if (A.occlusion) {
+                                    float m = 1e-4f * (fabsf(S.thr) + fabsf(no.x) + fabsf(no.y) + fabsf(no.z)) + 1e-6f;
+                                    nb = fminf(kInf, S.thr + m);
+                                    ns = S.thr - m;
+                                }
+                                n_shadow++;
+                                go = true;
+                                break;
+                            }
+                        }
+                        if (!go) {
+                            // ---- end of the bounce: PathTracer.cu:73-88
+                            S.res = add(S.res, mul(S.beta, S.le));
+                            const ModelRec &M = v.models[S.model];
+                            const Hit H = S.hit();
+                            float u[4];
+                            pixel_uniform4(v.pixmap[pl], S.draw - 1u - (uint32_t)L, u);
+                            v3 wi;
+                            float pdf;
+                            v3 f = rec_sample_f_y(H, M, S.wo_y, wi, pdf, u[0], u[1]);
+                            bool done = (pdf < 0.0001f || len_below_1e4(f));
+                            if (!done) {
+                                S.beta = mul(S.beta, divs(scale(f, fabsf(dot(wi, H.normal))), pdf));
+                                Ray nr = spawn_ray(H, wi);
+                                no = nr.o; nd = nr.d;
+                                if (bnc > 3) {
+                                    if (u[2] < 0.5f)
+                                        done = true;
+                                    else
+                                        S.beta = divs(S.beta, 1.0f - 0.5f);
+                                }
+                            }
+                            if (!done && bnc + 1 > A.max_depth) {
+                                S.draw += 1u;
+                                done = true;
+                            }
+                            if (done) {
+                                finalize_path(v, pl, S.res, v.cnt);
+                                v.rng_ctr[pl] = S.draw;
+                                alive = false;
+                            } else {
+                                bnc++;
+                                n_bounce++;
+                                ph = -1;
+                                go = true;
+                            }
+                        }
+                    }
+                }
+                if (go) {
+                    S.save(st);
+                    const v3 oo[2] = {no, no}, dd[2] = {nd, nd};
+                    const float bb[2] = {nb, 0.0f}, ss[2] = {ns, -1.0f};
+                    const bool lv[2] = {true, false};
+                    pair_set(w, oo, dd, bb, ss, lv, E);
+                    level = tv.top;
+                    g = 0;
+                    pend = (unsigned long long)expand(level, 0u) << (4 * level);
+                    walking = true;
+                }
+            }
+        }
+        // ---- one step of the walks under way (traverse_lane's loop body, one KIND of step per pass: lanes that expand a
+        // node group and lanes that test a triangle run different code, and a pass that did both would run each
+        // with the other's lanes idle; the kind more lanes wait for goes, the others keep their place)
+        uint32_t m = 0;
+        if (walking) {
+            m = (uint32_t)(pend >> (4 * level)) & 15u;
+            while (m == 0u && walking) {                     // groups that are done: back to their parents' (cheap)
+                level++;
+                g >>= 2;
+                walking = level <= tv.top;
+                m = walking ? (uint32_t)(pend >> (4 * level)) & 15u : 0u;
+            }
+        }
+        const bool want_tri = walking && level == 0, want_node = walking && level != 0;
+        const unsigned long long tri_m = __ballot(want_tri), node_m = __ballot(want_node);
+        if (tri_m | node_m) {
+            const bool do_tri = __popcll(tri_m) > __popcll(node_m);
+            if (do_tri ? want_tri : want_node) {
+                const int j = __builtin_ctz(m);
+                pend &= ~(1ull << (4 * level + j));
+                const uint32_t node = g * kTreeArity + (uint32_t)j;
+                if (do_tri) {
+                    const float4 *tp = (const float4 *)(A.T.tris + node);
+                    const float4 t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+                    TriRec T;
+                    T.ax = t0.x; T.ay = t0.y; T.az = t0.z; T.dn = t0.w;
+                    T.bx = t1.x; T.by = t1.y; T.bz = t1.z; T.S = t1.w;
+                    T.cx = t2.x; T.cy = t2.y; T.cz = t2.z; T.orig = __float_as_int(t2.w);
+                    T.nx = t3.x; T.ny = t3.y; T.nz = t3.z; T.qmax = t3.w;
+                    tri_test_pair(T, w, true, false);
+                    if (w.best.x < w.stop.x) w.bestp.x = -1.0f;  // occlusion form: the ray is over
+                } else {
+                    level--;
+                    g = node;
+                    pend |= (unsigned long long)expand(level, g) << (4 * level);
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        n_bounce += (uint32_t)__shfl_xor((int)n_bounce, o);
+        n_shadow += (uint32_t)__shfl_xor((int)n_shadow, o);
+    }
+    if (lane == 0) {
+        if (n_shadow) atomicAdd(&A.ctl->shadow_total, (unsigned long long)n_shadow);
+        if (n_bounce) atomicAdd(&A.ctl->bounce_total, (unsigned long long)n_bounce);
+    }
+}
+
 // ------------------------------------------------------------------ depth 0: whole batches of samples
 // With max_depth = 0 (primary hit + direct light, the benchmark mode) the samples of a pixel
 // depend on one another only through the closest hit of the camera ray: the pixel's Philox
@@ -3321,7 +3582,8 @@ bool launch_path(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, int m
         A.bq = *bq;
         A.bq.pairs = knobs.bounce_pairs;
         k_path<true, false, 3, true><<<g, kBlock, 0, s>>>(A, work, work_next, dynamic);
-        k_bounce<true><<<(uint32_t)std::max(max_blocks, 1) * 3u, kBlock, 0, s>>>(A);
+        if (knobs.bounce_queue >= 2) k_bounce_sm<true><<<(uint32_t)std::max(max_blocks, 1) * 3u, kBlock, 0, s>>>(A);
+        else                         k_bounce<true><<<(uint32_t)std::max(max_blocks, 1) * 3u, kBlock, 0, s>>>(A);
         return true;
     }
     if (v.cull) {

@@ -939,7 +939,7 @@ def test_lane_traversal_equals_wave_traversal(gpu_ctx_factory, monkeypatch):
     cam = CameraArgs.for_image(96, 64, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
     for scene in (soup, scenes.material_test_scene()[0]):
         frames = []
-        for knobs in ({"RT_LANE_TRAVERSAL": "0"}, {}, {"RT_BOUNCE_WAVES": "2"}, {"RT_BOUNCE_QUEUE": "1"}):
+        for knobs in ({"RT_LANE_TRAVERSAL": "0"}, {}, {"RT_BOUNCE_WAVES": "2"}, {"RT_BOUNCE_QUEUE": "1"}, {"RT_BOUNCE_QUEUE": "2"}):
             for k, val in knobs.items():
                 monkeypatch.setenv(k, val)
             ctx = gpu_ctx_factory(96, 64)
@@ -971,7 +971,8 @@ def test_bounce_queue_equals_one_kernel_form(gpu_ctx_factory, monkeypatch):
     spp, depth = 3, 12
     frames, counts = [], []
     for knobs in ({"RT_BOUNCE_QUEUE": "0"}, {"RT_BOUNCE_QUEUE": "1"}, {"RT_BOUNCE_QUEUE": "1", "RT_MAX_BLOCKS": "2"},
-                  {"RT_BOUNCE_QUEUE": "1", "RT_BOUNCE_PAIRS": "1"}):
+                  {"RT_BOUNCE_QUEUE": "1", "RT_BOUNCE_PAIRS": "1"}, {"RT_BOUNCE_QUEUE": "2"},
+                  {"RT_BOUNCE_QUEUE": "2", "RT_MAX_BLOCKS": "1"}):
         for k, val in knobs.items():
             monkeypatch.setenv(k, val)
         ctx = gpu_ctx_factory(cfg.width, cfg.height)
@@ -992,7 +993,7 @@ def test_bounce_queue_equals_one_kernel_form(gpu_ctx_factory, monkeypatch):
     check_images(frames[1], orc.render(cfg.scene, cfg.camera, cfg.width, cfg.height, spp=spp, max_depth=depth))
     # three ranks' partitions, gathered: the whole frame
     union = np.zeros_like(frames[1]["rgba"])
-    monkeypatch.setenv("RT_BOUNCE_QUEUE", "1")
+    monkeypatch.setenv("RT_BOUNCE_QUEUE", "2")
     part = gpu_ctx_factory(cfg.width, cfg.height)
     part.upload_scene(cfg.scene)
     part.set_camera(cfg.camera)

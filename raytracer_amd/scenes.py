@@ -361,12 +361,25 @@ def synthetic_environment(width=48, height=24, seed=11):
     return img
 
 
-def demo_scene_with_environment():
+def stb_ldr_to_hdr(rgba_u8):
+    """What stbi_loadf(file, .., 4) returns for an 8-bit image (stb_image.h stbi__ldr_to_hdr with its defaults
+    l2h_gamma = 2.2f, l2h_scale = 1.0f; the reference's call: kernel.cu:271): colour channels
+    (float)(pow(v / 255.0f, 2.2f) * 1.0f) -- the power taken in double --, alpha v / 255.0f."""
+    u = np.asarray(rgba_u8, dtype=np.uint8)
+    x = (u.astype(np.float32) / np.float32(255.0))
+    out = np.empty(u.shape, np.float32)
+    out[..., :3] = np.power(x[..., :3].astype(np.float64), np.float64(np.float32(2.2))).astype(np.float32)
+    out[..., 3] = x[..., 3]
+    return out
+
+
+def demo_scene_with_environment(env_image=None):
     """The reference's demo scene as it is (kernel.cu:268-313): two spheres, one two-sided
-    TriangleLight and one EnvironmentLight, light_size = {0, 0, 1, 1} -- with a synthetic image in
-    place of environment.png."""
+    TriangleLight and one EnvironmentLight, light_size = {0, 0, 1, 1}.  env_image: the float RGBA image
+    stbi_loadf returns for the reference's environment.png (tests/golden/make_golden.py decodes the file with PIL
+    and stb_ldr_to_hdr; the fixture carries the result); None: a synthetic image in its place."""
     scene = demo_scene()
-    scene.env_image = synthetic_environment()
+    scene.env_image = synthetic_environment() if env_image is None else np.ascontiguousarray(env_image, np.float32)
     return scene.normalise()
 
 

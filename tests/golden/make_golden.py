@@ -43,7 +43,7 @@ CASES = {
     "area": (("area", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 5)]),
     # every BRDF of material.cu, one model each
     "materials": (("materials", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (3, 6)]),
-    # the reference's demo scene with its environment light (a synthetic image) and the materials
+    # the reference's demo scene with its environment light (the reference's environment.png) and the materials
     # scene under one: EnvironmentLight + Distribution2D
     "demo_env": (("demo_env", {}), 160, 120, (40, 20, 120, 100), [(2, 0), (3, 6)]),
     "materials_env": (("materials_env", {}), 96, 64, (16, 8, 80, 56), [(2, 0), (2, 6)]),
@@ -54,6 +54,7 @@ CASES = {
 
 SCENE_FIELDS = ["tri_pos", "tri_nrm", "tri_model", "mesh_first", "mesh_count", "model_xf",
                 "model_mat_type", "model_color", "quad_coeff", "quad_type", "pl_pos", "pl_illum"]
+REFERENCE_ROOT = os.environ.get("RT_REFERENCE_ROOT", "/root/reference")   # read by THIS script only (fixture generation)
 OPTIONAL_SCENE_FIELDS = ["dl_dir", "dl_illum",        # absent from fixtures written before them
                          "tl_pos", "tl_illum", "tl_two_side", "tl_mat_type", "tl_color",
                          "model_param", "env_image", "tri_uv", "mesh_texture"]
@@ -94,7 +95,16 @@ def build_case(name):
         scene.env_image = scenes.synthetic_environment(32, 16, seed=5)
         cam = CameraArgs.for_image(w, h, near=0.5, pos=(0.0, 20.0, 60.0), lookat=(0.0, 0.0, -400.0))
     elif kind in ("demo", "demo_env"):
-        scene = scenes.demo_scene() if kind == "demo" else scenes.demo_scene_with_environment()
+        if kind == "demo":
+            scene = scenes.demo_scene()
+        else:
+            # the reference's own environment map, a data file beside its driver (kernel.cu:271-272 loads it with
+            # stbi_loadf(.., 4)): decoded here with PIL and converted the way stb does; the fixture carries the
+            # float image, so nothing reads the reference tree when the tests run
+            from PIL import Image
+            png = os.path.join(REFERENCE_ROOT, "src", "RayTracer", "environment.png")
+            scene = scenes.demo_scene_with_environment(
+                scenes.stb_ldr_to_hdr(np.asarray(Image.open(png).convert("RGBA"))))
         cam = CameraArgs.for_image(w, h)
     else:
         cfg = scenes.CONFIGS[kind](w, h, **kw)

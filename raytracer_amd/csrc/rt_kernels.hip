@@ -105,14 +105,14 @@ extern "C" void rt_debug_log(void *out, unsigned p0, unsigned n)
 // Diagnostic build (tools/build_variant.sh tick -DRT_TICKWAIT, tools/tick_report.py): how long k_batch's waves wait for
 // dispenser tickets.  Summed over the waves of all launches since the last reset, in s_memtime ticks:
 // 0 wave lifetime, 1 wait for tickets drawn one unit ahead, 2 wait for tickets drawn on the spot (a stage or band
-// change), 3 / 4 their numbers, 5 time in pick(), 6 calls of pick().
-__device__ unsigned long long g_tick[8];
+// change), 3 / 4 their numbers, 5 / 6 / 7 time in a unit's phases P + H, S and in its epilogue, 8 units.
+__device__ unsigned long long g_tick[16];
 extern "C" void rt_debug_tick(unsigned long long *out, int reset)
 {
     hipDeviceSynchronize();
-    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tick), sizeof(unsigned long long) * 8);
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tick), sizeof(unsigned long long) * 16);
     if (reset) {
-        unsigned long long z[8] = {};
+        unsigned long long z[16] = {};
         hipMemcpyToSymbol(HIP_SYMBOL(g_tick), z, sizeof(z));
     }
 }
@@ -2484,7 +2484,8 @@ enum : int {
     kDkInBand,                       // the unit's cost counts for its band's sum
     kDkBandCostLo, kDkBandCostHi, kDkCostLo, kDkCostHi,
     kDkHeavy, kDkEarly, kDkLate,     // the launch's cost thresholds (feedback)
-    kDkTick1, kDkTick2, kDkTickN1, kDkTickN2, kDkTickP, kDkTickNP,   // RT_TICKWAIT only
+    kDkTick1, kDkTick2, kDkTickN1, kDkTickN2,   // RT_TICKWAIT only
+    kDkTickA, kDkTickB, kDkTickC, kDkTickU,     // ... cycles in a unit's phases P + H, S, epilogue; units
     kDkWords = 32
 };
 
@@ -2506,6 +2507,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     RT_MARK(sp, 1);
     RT_COUNT(sp, 11);
     RT_STAMP(sp.unit_begin());
+    RT_TICK(const unsigned long long tk0 = __builtin_amdgcn_s_memtime());
 
     // ---------------- phase P: the camera rays' closest hits, records to LDS
     uint32_t pix[2], base_c[2], base_s[2], dhat[2];
@@ -2694,6 +2696,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 
+    RT_TICK(const unsigned long long tk1 = __builtin_amdgcn_s_memtime());
     // ---------------- phase S: lights, shadow rays, the pixels' running mean
     uint32_t ln = lane;
     asm volatile("" : "+v"(ln));
@@ -2820,6 +2823,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
         }
         RT_MARK(sp, 22);
     }
+    RT_TICK(const unsigned long long tk2 = __builtin_amdgcn_s_memtime());
     if (lane == 0 && dk[kDkDraw] == 1u)                      // the next unit's ticket, late form: back behind the epilogue
         ticket = atomicAdd(&work[dk[kDkCtr]], 1u);
     RT_MARK(sp, 21);
@@ -2932,6 +2936,9 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     // the next unit's phase P writes these rows: every lane's reads above must be done first
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
+    RT_TICK(const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
+            dk[kDkTickA] = dk[kDkTickA] + (uint32_t)(tk1 - tk0); dk[kDkTickB] = dk[kDkTickB] + (uint32_t)(tk2 - tk1);
+            dk[kDkTickC] = dk[kDkTickC] + (uint32_t)(tk3 - tk2); dk[kDkTickU] = dk[kDkTickU] + 1u);
     RT_MARK(sp, 10);
     RT_STAMP(sp.unit_end(unit, cost));
 }
@@ -3098,6 +3105,19 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(key >> 32));
         return (klo | khi) ? (int)(klo & 7u) : -1;
     };
+    // The slice of the late units with the most tickets left (-1: none): going round the eight slices in order
+    // costs a draw on the spot per slice, 6 us each at the very end of a wave's life.
+    auto pick_late = [&]() -> int {
+        const uint32_t y = lane & 7u, n_late = LS->n_late, late_per = (n_late + 7u) / 8u;
+        const uint32_t nun = y * late_per < n_late ? min(late_per, n_late - y * late_per) : 0u;
+        const uint32_t tickets = (nun + A.grab_late - 1u) / A.grab_late;
+        const uint32_t c = __hip_atomic_load(&work[kWorkLate + y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t key = tickets > c ? ((tickets - c) << 3) | y : 0u;
+        for (int o = 1; o < 8; o <<= 1)
+            key = max(key, (uint32_t)__shfl_xor((int)key, o));
+        key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+        return key ? (int)(key & 7u) : -1;
+    };
     uint32_t ticket = 0;
     RT_TICK(const unsigned long long tick_begin = __builtin_amdgcn_s_memtime());
     {
@@ -3106,7 +3126,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         D.band = xcd;
         dk[kDkBandCostLo] = 0u; dk[kDkBandCostHi] = 0u; dk[kDkCostLo] = 0u; dk[kDkCostHi] = 0u;
         dk[kDkHeavy] = heavy_cost; dk[kDkEarly] = early_cost; dk[kDkLate] = late_cost;
-        RT_TICK(dk[kDkTick1] = 0u; dk[kDkTick2] = 0u; dk[kDkTickN1] = 0u; dk[kDkTickN2] = 0u; dk[kDkTickP] = 0u; dk[kDkTickNP] = 0u);
+        RT_TICK(dk[kDkTick1] = 0u; dk[kDkTick2] = 0u; dk[kDkTickN1] = 0u; dk[kDkTickN2] = 0u; dk[kDkTickA] = 0u; dk[kDkTickB] = 0u; dk[kDkTickC] = 0u; dk[kDkTickU] = 0u);
         D.stage = wave_id < n_lists ? -1 : 0;
         if (D.stage == -1) {
             enter_list(D, n_lists);
@@ -3148,16 +3168,15 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
                 if (D.stage < 0) {
                     D.stage = 0;
                     enter_band(D, xcd);
-                } else if (D.stage == 7) {                    // this slice of the late units is used up: the next
-                    if (++D.late_helped >= 8u) {
+                } else if (D.stage == 7) {                    // this slice of the late units is used up: the fullest
+                    const int y = ++D.late_helped < 16u ? pick_late() : -1;
+                    if (y < 0) {
                         D.stage = 8;
                         break;
                     }
-                    enter_late(D, (xcd + D.late_helped) & 7u);
+                    enter_late(D, (uint32_t)y);
                 } else {
-                    RT_TICK(const unsigned long long tp0 = __builtin_amdgcn_s_memtime());
                     const int y = A.band_help ? pick() : ++D.helped < 8u ? (int)((xcd + D.helped) & 7u) : -1;
-                    RT_TICK(dk[kDkTickP] = desk(kDkTickP) + (uint32_t)(__builtin_amdgcn_s_memtime() - tp0); dk[kDkTickNP] = desk(kDkTickNP) + 1u);
                     if (y >= 0) {
                         D.stage = 1;
                         enter_band(D, (uint32_t)y);
@@ -3236,7 +3255,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         atomicAdd(&g_tick[0], __builtin_amdgcn_s_memtime() - tick_begin);
         atomicAdd(&g_tick[1], (unsigned long long)desk(kDkTick1)); atomicAdd(&g_tick[2], (unsigned long long)desk(kDkTick2));
         atomicAdd(&g_tick[3], (unsigned long long)desk(kDkTickN1)); atomicAdd(&g_tick[4], (unsigned long long)desk(kDkTickN2));
-        atomicAdd(&g_tick[5], (unsigned long long)desk(kDkTickP)); atomicAdd(&g_tick[6], (unsigned long long)desk(kDkTickNP));
+        atomicAdd(&g_tick[5], (unsigned long long)desk(kDkTickA)); atomicAdd(&g_tick[6], (unsigned long long)desk(kDkTickB));
+        atomicAdd(&g_tick[7], (unsigned long long)desk(kDkTickC)); atomicAdd(&g_tick[8], (unsigned long long)desk(kDkTickU));
     }
 #endif
     {

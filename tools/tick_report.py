@@ -28,13 +28,14 @@ def main():
                 ctx.reset(); ctx.render(spp, 0)
             L.rt_debug_tick(None, 1)
             ctx.reset(); ctx.render(spp, 0)
-            out = (C.c_uint64 * 8)()
+            out = (C.c_uint64 * 16)()
             L.rt_debug_tick(out, 0)
-            life, w1, w2, n1, n2, tp, npk = [int(out[i]) for i in range(7)]
+            life, w1, w2, n1, n2, ta, tb, tc, nu = [int(out[i]) for i in range(9)]
             print(f"{name} {spp} spp world {world}: wave lifetime {life} ticks over all waves")
             print(f"   tickets drawn a unit ahead: {n1:9d}  waited {100.0 * w1 / life:6.2f} % of lifetime, {w1 / max(n1, 1):8.1f} ticks each")
             print(f"   tickets drawn on the spot:  {n2:9d}  waited {100.0 * w2 / life:6.2f} % of lifetime, {w2 / max(n2, 1):8.1f} ticks each")
-            print(f"   pick():                     {npk:9d}  took   {100.0 * tp / life:6.2f} % of lifetime, {tp / max(npk, 1):8.1f} ticks each", flush=True)
+            print(f"   units {nu}: phases P + H {ta / max(nu, 1):9.0f} ticks each ({100.0 * ta / life:5.1f} %), phase S {tb / max(nu, 1):9.0f} ({100.0 * tb / life:5.1f} %), "
+                  f"epilogue + feedback {tc / max(nu, 1):9.0f} ({100.0 * tc / life:5.1f} %), outside units {100.0 * (life - ta - tb - tc) / life:5.1f} %", flush=True)
 
 
 if __name__ == "__main__":

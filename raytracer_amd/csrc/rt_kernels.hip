@@ -3147,7 +3147,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         D.stage = (int)desk(kDkStage); D.bias = desk(kDkBias); D.size = desk(kDkSize); D.nun = desk(kDkNun);
         D.grab = desk(kDkGrab); D.band = desk(kDkBand); D.helped = desk(kDkHelped); D.late_helped = desk(kDkLateHelped);
         D.k = desk(kDkK); D.d = desk(kDkD); D.list_kind = desk(kDkListKind); D.list_off = desk(kDkListOff); D.ctr = desk(kDkCtr);
-        const uint32_t n_tasks = n_tasks_of();
+        const uint32_t n_tasks = D.stage == -1 ? n_tasks_of() : 0u;   // (two loads from memory: only while on the lists)
         if (D.k >= D.grab || D.d * D.grab + D.k >= D.nun) {  // this ticket is used up: the one drawn meanwhile
             D.k = 0;
 #ifdef RT_TICKWAIT

@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 path with every rank on ONE GPU "
                          "(gather staged through host memory); not a measurement")
+    ap.add_argument("--collective-with-one-rank", action="store_true",
+                    help="with one GPU: run the N > 1 branch (process group, export, all-gather, "
+                         "all-reduces) with a world of one -- a rehearsal of that branch, not a bench line")
     ap.add_argument("--cpu-crop", type=int, nargs=2, default=None, metavar=("W", "H"))
     return ap.parse_args()
 
@@ -146,15 +149,24 @@ def main():
     import torch
     from raytracer_amd import abi, scenes
 
+    # --collective-with-one-rank: a rehearsal of the N > 1 branch where only one GPU is at hand -- the
+    # process group, the export into the collective's buffer, the all-gather, the barrier and the
+    # all-reduces all run, over RCCL, with a world of one
+    multi = world > 1 or a.collective_with_one_rank
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    dev = local_rank if (world > 1 and a.backend == "nccl") else 0
+    dev = local_rank if (multi and a.backend == "nccl") else 0
     cdev = "cuda" if a.backend == "nccl" else "cpu"      # where the collectives' tensors live
     torch.cuda.set_device(dev)
 
@@ -171,7 +183,7 @@ def main():
     n_local = ctx.local_pixel_count()
 
     gather = None
-    if world > 1:
+    if multi:
         from raytracer_amd.dist import FrameGather
         gather = FrameGather(cfg.width, cfg.height, world, 64, cdev, abi.partition_pixels)
         stage = torch.zeros_like(gather.local, device="cuda") if cdev == "cpu" else None
@@ -179,7 +191,7 @@ def main():
     def step():
         ctx.reset()                      # a fresh frame: counters, RNG streams, framebuffer
         ctx.render(spp, 0)
-        if world > 1:                    # final framebuffer gathered over xGMI (RCCL)
+        if multi:                        # final framebuffer gathered over xGMI (RCCL)
             # the previous step's gather (asynchronous, on torch's stream) still reads gather.local: it has had
             # a whole render to finish, this makes it certain before the buffer is overwritten
             torch.cuda.current_stream().synchronize()
@@ -191,7 +203,7 @@ def main():
             gather.gather(dist)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -209,7 +221,7 @@ def main():
     ctx.set_timing(False)
 
     rays_local = float(st.primary_rays + st.shadow_rays)
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -299,6 +311,14 @@ def main():
                                  "frac_of_valu_pipe_hi": mix["pipe_cycles_hi"] / avail,
                                  "note": "mix-weighted with measured prices (2 / 4 / 8 cycles per wave64 instruction), not a flat "
                                          "4 cycles per instruction; what is left is issue latency of four waves per SIMD (DESIGN.md 5)"}
+        if a.collective_with_one_rank and world == 1:
+            # the frame the all-gather assembled against the context's own framebuffer, bit for bit
+            whole = gather.frame[:-1].view(cfg.height, cfg.width, 4).cpu().numpy()
+            mine = ctx.read_framebuffer()["rgba"]
+            out["collective_rehearsal"] = {
+                "backend": a.backend, "world": 1,
+                "frame_equals_framebuffer": bool(np.array_equal(whole.view(np.uint32), mine.view(np.uint32))),
+                "note": "the N > 1 branch run with a world of one; not a scaling figure"}
         if world == 1 and not a.no_cpu:
             crop = tuple(a.cpu_crop) if a.cpu_crop else {"c1": (640, 480), "c2": (1600, 900),
                                                          "c3": (192, 108), "c4": (32, 18),
@@ -308,7 +328,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

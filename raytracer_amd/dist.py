@@ -36,7 +36,7 @@ class FrameGather:
     def gather(self, dist=None):
         """`self.local[:n_local]` must hold this rank's RGBA; returns the full frame tensor
         [H, W, 4] (valid on every rank: an all-gather keeps the ranks symmetric)."""
-        if self.world > 1:
+        if dist is not None:             # also with a world of one: the collective itself runs
             dist.all_gather_into_tensor(self.gathered, self.local)
         else:
             self.gathered.copy_(self.local)

@@ -64,3 +64,29 @@ def test_two_ranks_render_export_gather(tmp_path, kind):
     assert frame.shape == ref.shape
     assert np.array_equal(frame.view(np.uint32), ref.view(np.uint32))
     assert (ref[..., :3] > 0).any()
+
+
+def test_bench_collective_branch_over_rccl_with_one_rank():
+    """bench.py's N > 1 branch (nccl = RCCL process group, export into the collective's device buffer,
+    all_gather_into_tensor, barrier, all-reduces) run on the one GPU at hand with a world of one: the
+    frame the all-gather assembled equals the context's framebuffer bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c3", "--width", "320",
+                        "--height", "200", "--spp", "3", "--steps", "2", "--warmup", "1", "--no-cpu",
+                        "--collective-with-one-rank"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    reh = out["collective_rehearsal"]
+    assert reh["backend"] == "nccl" and reh["frame_equals_framebuffer"] is True

@@ -106,13 +106,16 @@ extern "C" void rt_debug_log(void *out, unsigned p0, unsigned n)
 // dispenser tickets.  Summed over the waves of all launches since the last reset, in s_memtime ticks:
 // 0 wave lifetime, 1 wait for tickets drawn one unit ahead, 2 wait for tickets drawn on the spot (a stage or band
 // change), 3 / 4 their numbers, 5 / 6 / 7 time in a unit's phases P + H, S and in its epilogue, 8 units.
-__device__ unsigned long long g_tick[16];
+// 16 + 4 k ..: the same three phase sums and the units by where the unit came from, k = 0 a listed pixel, 1 an early
+// unit, 2 the wave's own band, 3 a band it helps, 4 the late units, 5 / 6 / 7 k = 2 / 3 / 4 again for the wave's
+// first four units only.
+__device__ unsigned long long g_tick[48];
 extern "C" void rt_debug_tick(unsigned long long *out, int reset)
 {
     hipDeviceSynchronize();
-    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tick), sizeof(unsigned long long) * 16);
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tick), sizeof(unsigned long long) * 48);
     if (reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[48] = {};
         hipMemcpyToSymbol(HIP_SYMBOL(g_tick), z, sizeof(z));
     }
 }
@@ -2486,7 +2489,13 @@ enum : int {
     kDkHeavy, kDkEarly, kDkLate,     // the launch's cost thresholds (feedback)
     kDkTick1, kDkTick2, kDkTickN1, kDkTickN2,   // RT_TICKWAIT only
     kDkTickA, kDkTickB, kDkTickC, kDkTickU,     // ... cycles in a unit's phases P + H, S, epilogue; units
+#ifdef RT_TICKWAIT
+    kDkTickBy = 32,                              // ... the same by where the unit came from: 8 x (A, B, C, units)
+    kDkTickFrom = 64,                            // where this unit came from
+    kDkWords = 72
+#else
     kDkWords = 32
+#endif
 };
 
 template <bool CULL, bool OWN_BASES>
@@ -2938,7 +2947,9 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     asm volatile("" ::: "memory");
     RT_TICK(const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
             dk[kDkTickA] = dk[kDkTickA] + (uint32_t)(tk1 - tk0); dk[kDkTickB] = dk[kDkTickB] + (uint32_t)(tk2 - tk1);
-            dk[kDkTickC] = dk[kDkTickC] + (uint32_t)(tk3 - tk2); dk[kDkTickU] = dk[kDkTickU] + 1u);
+            dk[kDkTickC] = dk[kDkTickC] + (uint32_t)(tk3 - tk2); dk[kDkTickU] = dk[kDkTickU] + 1u;
+            { uint32_t *const by = dk + kDkTickBy + 4u * dk[kDkTickFrom];
+              by[0] = by[0] + (uint32_t)(tk1 - tk0); by[1] = by[1] + (uint32_t)(tk2 - tk1); by[2] = by[2] + (uint32_t)(tk3 - tk2); by[3] = by[3] + 1u; });
     RT_MARK(sp, 10);
     RT_STAMP(sp.unit_end(unit, cost));
 }
@@ -3126,7 +3137,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         D.band = xcd;
         dk[kDkBandCostLo] = 0u; dk[kDkBandCostHi] = 0u; dk[kDkCostLo] = 0u; dk[kDkCostHi] = 0u;
         dk[kDkHeavy] = heavy_cost; dk[kDkEarly] = early_cost; dk[kDkLate] = late_cost;
-        RT_TICK(dk[kDkTick1] = 0u; dk[kDkTick2] = 0u; dk[kDkTickN1] = 0u; dk[kDkTickN2] = 0u; dk[kDkTickA] = 0u; dk[kDkTickB] = 0u; dk[kDkTickC] = 0u; dk[kDkTickU] = 0u);
+        RT_TICK(dk[kDkTick1] = 0u; dk[kDkTick2] = 0u; dk[kDkTickN1] = 0u; dk[kDkTickN2] = 0u; dk[kDkTickA] = 0u; dk[kDkTickB] = 0u; dk[kDkTickC] = 0u; dk[kDkTickU] = 0u;
+                for (int i = kDkTickBy; i < kDkWords; i++) dk[i] = 0u);
         D.stage = wave_id < n_lists ? -1 : 0;
         if (D.stage == -1) {
             enter_list(D, n_lists);
@@ -3225,6 +3237,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         dk[kDkListKind] = D.list_kind; dk[kDkListOff] = D.list_off; dk[kDkCtr] = D.ctr;
         dk[kDkDraw] = last_of_ticket ? (draw_early ? 2u : 1u) : 0u;
         dk[kDkInBand] = (D.stage == 0 || D.stage == 1) ? 1u : 0u;
+        RT_TICK({ const uint32_t from = D.stage == -1 ? (idx < n_tasks ? 0u : 1u) : D.stage == 0 ? 2u : D.stage == 1 ? 3u : 4u;
+                  dk[kDkTickFrom] = from >= 2u && desk(kDkTickU) < 4u ? from + 3u : from; });
         asm volatile("" ::: "memory");
         if (prio)
             __builtin_amdgcn_s_setprio(3);
@@ -3257,6 +3271,8 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         atomicAdd(&g_tick[3], (unsigned long long)desk(kDkTickN1)); atomicAdd(&g_tick[4], (unsigned long long)desk(kDkTickN2));
         atomicAdd(&g_tick[5], (unsigned long long)desk(kDkTickA)); atomicAdd(&g_tick[6], (unsigned long long)desk(kDkTickB));
         atomicAdd(&g_tick[7], (unsigned long long)desk(kDkTickC)); atomicAdd(&g_tick[8], (unsigned long long)desk(kDkTickU));
+        for (int i = 0; i < 32; i++)
+            if (dk[kDkTickBy + i]) atomicAdd(&g_tick[16 + i], (unsigned long long)dk[kDkTickBy + i]);
     }
 #endif
     {

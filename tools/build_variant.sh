@@ -10,7 +10,10 @@ cd "$(dirname "$0")/../raytracer_amd/csrc"
 O=../../build/$NAME
 mkdir -p $O
 HIPFLAGS="$* --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -Wno-bitwise-instead-of-logical -Wno-unused-value"
-/opt/rocm/bin/hipcc $HIPFLAGS -c rt_kernels.hip -o $O/rt_kernels.o
+mkdir -p $O/tmp
+/opt/rocm/bin/hipcc $HIPFLAGS -save-temps=obj -c rt_kernels.hip -o $O/tmp/rt_kernels.o
+python3 ../../tools/isa_spill_lint.py $O/tmp/rt_kernels-hip-amdgcn-amd-amdhsa-gfx950.s || echo "WARNING: this variant has spill code under a partial lane mask (tools/isa_spill_lint.py): its frames cannot be trusted"
+cp $O/tmp/rt_kernels.o $O/rt_kernels.o
 /opt/rocm/bin/hipcc $HIPFLAGS -c rt_context.hip -o $O/rt_context.o
 g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread -c rt_upload.cpp -o $O/rt_upload.o
 g++ -O2 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -pthread -c rt_hostio.cpp -o $O/rt_hostio.o

@@ -28,7 +28,7 @@ def main():
                 ctx.reset(); ctx.render(spp, 0)
             L.rt_debug_tick(None, 1)
             ctx.reset(); ctx.render(spp, 0)
-            out = (C.c_uint64 * 16)()
+            out = (C.c_uint64 * 48)()
             L.rt_debug_tick(out, 0)
             life, w1, w2, n1, n2, ta, tb, tc, nu = [int(out[i]) for i in range(9)]
             print(f"{name} {spp} spp world {world}: wave lifetime {life} ticks over all waves")
@@ -36,6 +36,11 @@ def main():
             print(f"   tickets drawn on the spot:  {n2:9d}  waited {100.0 * w2 / life:6.2f} % of lifetime, {w2 / max(n2, 1):8.1f} ticks each")
             print(f"   units {nu}: phases P + H {ta / max(nu, 1):9.0f} ticks each ({100.0 * ta / life:5.1f} %), phase S {tb / max(nu, 1):9.0f} ({100.0 * tb / life:5.1f} %), "
                   f"epilogue + feedback {tc / max(nu, 1):9.0f} ({100.0 * tc / life:5.1f} %), outside units {100.0 * (life - ta - tb - tc) / life:5.1f} %", flush=True)
+            names = ["listed pixel", "early unit", "own band", "helped band", "late units", "own band, first 4", "helped band, first 4", "late, first 4"]
+            for k, nm in enumerate(names):
+                a, b, c, n = [int(out[16 + 4 * k + i]) for i in range(4)]
+                if n:
+                    print(f"   {nm:22s} {n:8d} units ({100.0 * (a + b + c) / life:5.1f} % of lifetime): P + H {a / n:8.0f}  S {b / n:8.0f}  E {c / n:8.0f}  all {(a + b + c) / n:8.0f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -179,7 +179,7 @@ struct Knobs {
                                  // 8 measured 13 % slower on C3 -- too many units out of band order --, 16..48 alike)
     int draw_early = 0;          // RT_DRAW_EARLY=1: the next unit's ticket is drawn at the unit's start while its dispenser is far from
                                  // its end (measured: no difference, C3 13.67 / C4 55.2 ms either way, so the simpler form is the default)
-    int grab = 1;                // RT_GRAB: units a wave takes per ticket of a band's dispenser
+    int grab = 0;                // RT_GRAB: units a wave takes per ticket of a band's dispenser (0: by the launch's units per wave)
     int grab_late = 4;           // RT_GRAB_LATE: ... of the late units' dispenser
     int late_x16 = 4;            // RT_LATE_X16: k_batch keeps units of <= this many sixteenths of the mean unit cost for last (0: off)
     int band_help = 1;           // RT_BAND_HELP=0: an XCD that has used its band up helps the others' in fixed cyclic order

@@ -2500,7 +2500,7 @@ enum : int {
 
 template <bool CULL, bool OWN_BASES>
 __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &env, uint32_t unit,
-                                           uint32_t only_px, uint32_t lane, uint32_t *col, uint32_t *dk,
+                                           uint32_t only_px, uint32_t lane, uint32_t *col, uint32_t *col0, uint32_t *dk,
                                            uint32_t *__restrict__ work, uint32_t &ticket, Stamps &sp)
 {
     // only_px = kAllPixels: the whole unit; else only its pixel `only_px` (a listed unit, split by pixel).
@@ -2509,7 +2509,7 @@ __device__ __forceinline__ void fused_unit(const BatchArgs &A, const ChunkEnv &e
     const float E = A.T.tv.extent;
     const uint32_t px_log2 = 7u - A.ss_log2, px_mask = (1u << px_log2) - 1u, ss = 1u << A.ss_log2;
     const uint32_t p_end = A.p0 + A.n;
-    uint32_t *const col0 = col - lane;                      // column of this wave's lane 0
+    // (col0: the column of this wave's lane 0 -- the same for every lane, and handed in as such: a scalar register)
     uint32_t *const tmp = col + 2 * kRecRows * kBlock;       // this lane's phase rows
     uint32_t *const tmp0 = col0 + 2 * kRecRows * kBlock;
     uint32_t cost = 0;
@@ -3002,8 +3002,14 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
                                                      uint32_t *__restrict__ work_next)
 {
     __shared__ uint32_t s_lds[kFuseRows][kBlock];
-    uint32_t *col = &s_lds[0][threadIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
+    // the wave's first column and its desk: wave-uniform, so from a scalar register (derived from threadIdx.x alone
+    // they sit in vector registers that get spilled, and their reloads are what waits for a ticket draw: DESIGN.md 4.1)
+    // (four-wave build: C3 -1.7 %, C4 -1.4 % of the step; the five-wave build spills more with it, 77 -> 99 registers,
+    // and C5 loses 0.7 %: it keeps the vector form)
+    const uint32_t wave_in_block = WAVES >= 5 ? threadIdx.x >> 6 : (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *col = WAVES >= 5 ? &s_lds[0][threadIdx.x] : &s_lds[0][wave_in_block * 64u] + lane;
+    uint32_t *const col0 = col - lane;
     ChunkEnv env;
     env.lvloff = A.T.tv.level_off[lane & (kMaxLevels - 1)];
     env.feedback = false; env.heavy_cost = 0xffffffffu; env.mean_cost = 0u;
@@ -3022,7 +3028,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
     const uint32_t px_log2 = 7u - A.ss_log2, px = 1u << px_log2;
     const uint32_t n_units = (A.n + px - 1u) / px;
     __shared__ uint32_t s_desk[kBlock / 64u][kDkWords];
-    uint32_t *const dk = s_desk[threadIdx.x >> 6];            // (plain LDS accesses, fenced by compiler barriers: a volatile
+    uint32_t *const dk = s_desk[wave_in_block];            // (plain LDS accesses, fenced by compiler barriers: a volatile
                                                              // pointer loses its address space and turns into flat accesses)
     auto desk = [&](int i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)dk[i]); };
     // What the previous launch of this shape found costly: those units first, one pixel per task.
@@ -3249,7 +3255,7 @@ __global__ __launch_bounds__(kBlock, WAVES) void k_batch(const BatchArgs A, uint
         const unsigned long long cost_before = desk(kDkCostLo);
         const bool is_task = D.stage == -1 && idx < n_tasks;
 #endif
-        fused_unit<CULL, WAVES >= 5>(A, env, unit, only_px, lane, col, dk, work, ticket, sp);
+        fused_unit<CULL, WAVES >= 5>(A, env, unit, only_px, lane, col, col0, dk, work, ticket, sp);
         if (prio)
             __builtin_amdgcn_s_setprio(0);
 #ifdef RT_STAMPS

@@ -87,6 +87,7 @@ struct Lane {
     BatchLists *blists = nullptr;                  // two: a launch's k_batch zeroes the other for the next launch's k_classify
     uint32_t bl_seq = 0;
     uint32_t bfb_shape[3] = {0, 0, 0};              // 1 + ss_log2 of the launch that wrote each set (0: none)
+    uint32_t bfb_run = 0;                           // launches of one shape in a row so far
     uint32_t *bflag[3] = {nullptr, nullptr, nullptr};
     FbCounts *bcnt = nullptr;            // [3]
     uint32_t bfb_slots = 0;
@@ -260,6 +261,7 @@ int alloc_feedback(rt_context *c, Lane &L)
     RT_HIP(c, hipMemset(L.blists, 0, 2 * sizeof(BatchLists)));
     L.bl_seq = 0;
     L.bfb_shape[0] = L.bfb_shape[1] = L.bfb_shape[2] = 0;
+    L.bfb_run = 0;
     L.bfb_slots = (uint32_t)units;
     L.bfb_seq = 0;
     return RT_OK;
@@ -369,13 +371,16 @@ int next_batch_feedback(rt_context *c, Lane &L, BatchFeedback &f, uint32_t ss_lo
     if (!c->batch_feedback) {                // ordering off: every unit is ordinary, nothing is recorded
         f.cnt_w = nullptr; f.heavy_w = nullptr; f.early_w = nullptr; f.flag_w = nullptr;
         f.cnt_z = nullptr; f.flag_z = nullptr;
-        f.flags_valid = 0;
+        f.flags_valid = 0; f.settled = 0;
         return RT_OK;
     }
     f.cnt_w = L.bcnt + w; f.heavy_w = L.bheavy[w]; f.early_w = L.bearly[w]; f.flag_w = L.bflag[w];
     f.cnt_z = L.bcnt + z; f.flag_z = L.bflag[z];
     // the lists of set r are for this launch only if a launch of the same shape (samples per wave) wrote them
     f.flags_valid = L.bfb_shape[r] == ss_log2 + 1u ? 1u : 0u;
+    // the first launch of a shape flags nothing (it has no costs to set thresholds by), so the lists count from the third
+    L.bfb_run = f.flags_valid ? L.bfb_run + 1u : 0u;
+    f.settled = L.bfb_run >= 2u ? 1u : 0u;
     L.bfb_shape[w] = ss_log2 + 1u;
     L.bfb_shape[z] = 0;
     L.bfb_seq++;

@@ -108,6 +108,7 @@ struct BatchFeedback {
     FbCounts *cnt_z;                     // the set after `w`: zeroed by k_classify for the launch that will write it
     uint32_t *flag_z;                    // (nullptr: no feedback)
     uint32_t flags_valid;                // 1: flag_r was written by a launch of this shape; 0: every unit is ordinary
+    uint32_t settled;                    // 1: ... and that launch had thresholds of its own to flag by (the third launch of a shape on)
 };
 
 // Bounce queue (rt_render with max_depth > 0 over a deep tree).  A sample is two launches: k_path's EMIT build

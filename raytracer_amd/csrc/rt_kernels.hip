@@ -3701,11 +3701,13 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
     // Units per ticket of a band's dispenser.  A draw costs the unit that makes it 2-5 us (the epilogue's first reload of
     // a spilled register waits for it: DESIGN.md 4.1), a ticket of several units makes the launch's tail that many units
     // long.  By default (RT_GRAB=0) several only where a wave has many short units to do -- the four-wave build at more
-    // than 192 units per wave (C3 whole: 5 per ticket, -2 % of the step; a half, a quarter or an eighth of it: 1);
+    // than 192 units per wave (C3 whole: 5 per ticket, -2 % of the step; a half, a quarter or an eighth of it: 1), and
+    // only once the lists are in use (from the third launch of a shape: before, costly units are met in band order
+    // and a ticket of several makes the tail long -- C3's first two launches 14.9 -> 16.5-17.7 ms);
     // C4's units are long enough not to feel the draw, C5's (five-wave build) so long that the tail costs more.
     const uint32_t units_per_wave = units / std::max(1u, g * (kBlock / 64u));
     A.grab = knobs.grab > 0 ? (uint32_t)std::min(64, knobs.grab)
-                            : (waves == 5 || units_per_wave < 192u ? 1u : std::min(8u, units_per_wave / 48u));
+                            : (waves == 5 || units_per_wave < 192u || !A.fb.settled ? 1u : std::min(8u, units_per_wave / 48u));
     A.grab_late = (uint32_t)std::min(64, std::max(1, knobs.grab_late));
     A.band_units = batch_band_units(units);
     A.draw_early_ok = knobs.draw_early != 0;

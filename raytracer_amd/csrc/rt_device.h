@@ -129,18 +129,18 @@ __device__ __forceinline__ bool tri_hit(const TriRec &T, const v3 &o, const v3 &
     return true;
 }
 
-// ------------------------------------------------------------------ packed pairs
-// Two rays per lane share every wave-uniform operand; ext_vector float2 arithmetic
-// compiles to v_pk_{mul,add}_f32 (IEEE, no contraction), i.e. the same bits as the
-// scalar code above at half the issue slots.
-#ifndef RT_UNPACKED
+// ------------------------------------------------------------------ ray pairs
+// Two rays per lane share every wave-uniform operand.  Their arithmetic is written as plain fp32 instructions, one
+// per ray: a v_pk_*_f32 occupies the SIMD for four cycles like its two halves (tools/valu_microbench.hip), and with
+// packed ops in the stream plain ops no longer issue beside the half-rate ones (v_max / v_min / v_cmp /
+// v_cndmask); without them they do.  Measured at the round's end: C3 -2.2 %, C4 -1.5 %, C2 -1.1 %, C5 -0.3 %
+// of the step against the packed form (profiles/r03_ab_unpacked.txt), same bits.  The packed form -- ext_vector
+// float2 arithmetic, v_pk_{mul,add,fma}_f32 -- stays as the A/B build: tools/build_variant.sh packed -DRT_PACKED
+// -fslp-vectorize (the product is compiled with -fno-slp-vectorize so that the compiler does not pair them up again).
+#ifdef RT_PACKED
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 #else
-// A/B build (tools/build_variant.sh unpacked -DRT_UNPACKED -fno-slp-vectorize): the same arithmetic as
-// plain fp32 instructions, one per ray.  tools/valu_microbench.hip: a v_pk_*_f32 occupies the SIMD for four
-// cycles like two plain ops, and with packed ops in the stream plain ops no longer issue beside the
-// half-rate ones (v_max / v_min / v_cmp / v_cndmask); without them they do.
 struct f2 { float x, y; };
 __device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }

@@ -20,10 +20,12 @@ SQC=SQC_DCACHE_REQ,SQC_DCACHE_HITS,SQC_DCACHE_MISSES,SQC_DCACHE_MISSES_DUPLICATE
 L2=TCC_HIT_sum,TCC_MISS_sum,TCC_REQ_sum
 for c in $CONFIGS; do
   case $c in
-    c2) B="--config c2 --steps 5 --warmup 2";           A="--config c2 --steps 2 --warmup 1 --no-cpu";;
-    c3) B="--config c3 --steps 3 --warmup 1";           A="--config c3 --steps 1 --warmup 1 --no-cpu";;
-    c4) B="--config c4 --steps 2 --warmup 1";           A="--config c4 --steps 1 --warmup 1 --no-cpu";;
-    c5) B="--config c5 --steps 2 --warmup 1";           A="--config c5 --steps 1 --warmup 1 --no-cpu";;
+    # (k_batch's feedback settles with the third launch of a shape: two warm-up steps everywhere, and enough timed
+    # ones in the traced runs that the two slower launches weigh little in the per-kernel averages)
+    c2) B="--config c2 --steps 5 --warmup 2";           A="--config c2 --steps 5 --warmup 2 --no-cpu";;
+    c3) B="--config c3 --steps 5 --warmup 2";           A="--config c3 --steps 18 --warmup 2 --no-cpu";;
+    c4) B="--config c4 --steps 3 --warmup 2";           A="--config c4 --steps 6 --warmup 2 --no-cpu";;
+    c5) B="--config c5 --steps 2 --warmup 2";           A="--config c5 --steps 2 --warmup 2 --no-cpu";;
     *)  B="--config $c --steps 3 --warmup 1";           A="--config $c --steps 1 --warmup 1 --no-cpu";;
   esac
   echo "== $c: bench"; date +%T

@@ -5,8 +5,8 @@ classes of a launch with the per-class SIMD cycles tools/valu_microbench.hip mea
   python tools/valu_ceiling.py profiles/r03_valu_mix.json c3=profiles/r03_c3_mix_unpacked.txt ...
 
 Input: tools/pmc_summary.py summaries of the per-class SQ counters (tools/r03_mix.sh) taken on the UNPACKED
-build of the library (tools/build_variant.sh unpacked -DRT_UNPACKED -fno-slp-vectorize): the same arithmetic with
-every v_pk_*_f32 written as two plain instructions.  The counters put a packed op in the same class as a plain
+build of the library (since the round's end the product itself; before: tools/build_variant.sh unpacked): the
+arithmetic of the ray pairs with every v_pk_*_f32 written as two plain instructions.  The counters put a packed op in the same class as a plain
 one, so only that build's counts can be priced; a packed op occupies the SIMD like its two plain halves
 (microbench: 4 cycles against 2 + 2) and the two builds run at the same speed (profiles/r03_ab_unpacked.txt),
 so the pipe time is the product's too.

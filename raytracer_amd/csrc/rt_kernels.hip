@@ -3675,7 +3675,6 @@ static BatchArgs batch_args(const DevView &v, uint32_t p0, uint32_t n, uint32_t 
 }
 
 constexpr size_t kLastLevelCacheBytes = 256u << 20;
-constexpr size_t kL2Bytes = 32u << 20;                      // eight XCDs x 4 MB
 
 void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint32_t n_samples,
                   int cnt0, int max_blocks, Ctl *ctl, uint32_t *work, uint32_t *work_next,
@@ -3693,13 +3692,10 @@ void launch_batch(hipStream_t s, const DevView &v, uint32_t p0, uint32_t n, uint
     // -- its spilled registers' scratch (43 MB over the chip) no longer fits the L2s -- and a small
     // partition, which is as long as its longest unit, gets slower (an eighth of C3 2.36 -> 2.42 ms).
     const size_t scene_bytes = ((size_t)v.tree.level_off[v.tree.top] + 1u) * sizeof(NodeGroup) + (size_t)v.n_tris * sizeof(TriRec);
-    // (Since the ray pairs' arithmetic is written out per ray the five-wave build spills 39 registers, not 77, and also
-    // pays over a scene beyond the L2s -- 32 MB -- when a wave has a few hundred units to do: C4 whole 197.3 -> 193.0 ms,
-    // half of it -1 %, a quarter equal, an eighth +2 %; C3, 9 MB, stays with four: 12.56 against 12.79 ms.)
-    const uint32_t units_per_wave5 = units / ((uint32_t)std::max(max_blocks, 1) * 5u * (kBlock / 64u));
-    const int waves = knobs.batch_waves ? (knobs.batch_waves >= 5 ? 5 : 4)
-                    : scene_bytes > kLastLevelCacheBytes ? 5
-                    : scene_bytes > kL2Bytes && units_per_wave5 >= 256u ? 5 : 4;
+    // (Since the ray pairs' arithmetic is written out per ray the five-wave build spills 39 registers, not 77, and would
+    // also pay over C4 -- 115 MB, beyond the L2s: whole frame 197.3 -> 193.0 ms, an eighth +2 % -- but its scratch, 52 MB
+    // over the chip, does not fit the L2s: 32 GB of HBM traffic per launch instead of 2.0.  Not taken for 2 %.)
+    const int waves = knobs.batch_waves ? (knobs.batch_waves >= 5 ? 5 : 4) : scene_bytes > kLastLevelCacheBytes ? 5 : 4;
     const uint32_t g = batch_grid(units, (uint32_t)std::max(max_blocks, 1) * (uint32_t)waves, knobs);
     A.task_prio = knobs.task_prio != 0;
     A.early_x4 = (uint32_t)std::max(0, knobs.early_x4);

@@ -34,6 +34,10 @@ def lint(path):
             if at_top and (t.startswith("scratch_") or t.startswith("buffer_")):
                 pending.append((no, t.split(";")[0].strip()))
             continue
+        # (kernels with the whole register file to one wave spill into AGPRs: the copies are lane-masked just the same)
+        if at_top and re.match(r"v_accvgpr_(write|read)_b32", t):
+            pending.append((no, t.split(";")[0].strip()))
+            continue
         if re.match(r"s_or_b64\s+exec,\s*exec,", t):
             for p in pending:
                 bad.append((kernel, block, p[0], p[1], no))
